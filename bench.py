@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the cu2rec hot path on MI355X: SGD updates/sec (+ test RMSE), ML-20M shape, f=100.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one reference iteration: one SGD update for every user with at least one rating
+(sgd.cu:27-37), i.e. one launch of the SGD kernel over the rank's users.  Inputs (CSR, P, Q,
+biases) are resident in HBM before the timed region.  For N > 1 every rank holds its own
+ML-20M-sized user population (weak scaling; same item set) and the replicas of Q / item_bias are
+reconciled by one RCCL all-reduce every `--sync-every` steps (default: one epoch = nnz / users
+steps), inside the timed region.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     HBM roofline of the SGD kernel: algorithmic bytes per launch (16 f + 32 per update,
+               SURVEY.md section 8d) / average kernel duration measured here with HIP events.
+  cpu_baseline the reference's own CPU twin (oracle/_ref/mf_cpu, kind "reference") timed on a
+               bounded sample of the same workload on this box's host cores, plus the oracle port
+               with the counter-based sampler ("port").
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def load_dataset(name, seed, rank, barrier):
+    """Synthetic set with the named shape; generated once per box and cached under /tmp."""
+    from cu2rec_amd import synth
+    from cu2rec_amd.api import HostCSR
+    path = os.path.join(tempfile.gettempdir(), "cu2rec_synth_%s_%d.npz" % (name, seed))
+    if rank == 0 and not os.path.exists(path):
+        tr, te = synth.make_named(name, seed=seed)
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, tr_indptr=tr.indptr, tr_indices=tr.indices, tr_data=tr.data, te_indptr=te.indptr,
+                 te_indices=te.indices, te_data=te.data, shape=np.array([tr.rows, tr.cols]),
+                 gb=np.array([tr.global_bias], np.float32))
+        os.replace(tmp, path)
+    barrier()
+    z = np.load(path)
+    rows, cols = (int(v) for v in z["shape"])
+    gb = float(z["gb"][0])
+    return (HostCSR(z["tr_indptr"], z["tr_indices"], z["tr_data"], rows, cols, gb),
+            HostCSR(z["te_indptr"], z["te_indices"], z["te_data"], rows, cols, gb))
+
+
+def cpu_baseline(train, test, f, hyper, budget_s=12.0):
+    """Reference CPU twin (if its binary travelled) and the oracle port, on bounded samples."""
+    from cu2rec_amd import synth
+    from oracle import oracle as orc
+    out = {}
+    # ---- oracle port, counter-based sampler, 1 thread: whole training set, a few iterations
+    o_tr = orc.CSR(train.indptr, train.indices, train.data, train.rows, train.cols, train.global_bias)
+    P, Q, ub, ib = orc.init_model(train.rows, train.cols, f)
+    users = int(np.count_nonzero(np.diff(train.indptr)))
+    t0 = time.perf_counter()
+    orc.sgd_iterations(o_tr, P, Q, ub, ib, train.global_bias, hyper, 42, 0, 1)
+    one = time.perf_counter() - t0
+    iters = int(max(1, min(200, (budget_s / 2) / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    orc.sgd_iterations(o_tr, P, Q, ub, ib, train.global_bias, hyper, 42, 1, iters)
+    dt = time.perf_counter() - t0
+    port = {"value": users * iters / dt, "unit": "updates/s", "cores": 1, "kind": "port",
+            "sample": "oracle/cu2rec_oracle.c (mf_sequential.cu:102-143 with the Philox sampler), full training set, "
+                      "%d iterations, f=%d, gcc -O3 -ffp-contract=off" % (iters, f)}
+    # ---- the reference's own binary on a user subsample written as CSV
+    exe = orc.ref_binary("mf_cpu")
+    if exe:
+        n_users = min(train.rows, 6000)
+        sub_tr, sub_te = train.slice_users(0, n_users), test.slice_users(0, n_users)
+        iters_ref = 30
+        with tempfile.TemporaryDirectory() as td:
+            ptr, pte, pcfg = os.path.join(td, "tr.csv"), os.path.join(td, "te.csv"), os.path.join(td, "c.cfg")
+            synth.write_csv(ptr, sub_tr)
+            synth.write_csv(pte, sub_te)
+            with open(pcfg, "w") as fh:
+                fh.write("0 %d %d %g 42 %g %g %g %g\n" % ((iters_ref, f) + tuple(hyper)))
+            res = subprocess.run([exe, "-c", pcfg, ptr, pte], stdout=subprocess.PIPE, text=True, timeout=600)
+        m = re.search(r"Time taken for (\d+) of iterations is ([0-9.]+)", res.stdout)
+        if res.returncode == 0 and m and float(m.group(2)) > 0:
+            users_sub = int(np.count_nonzero(np.diff(sub_tr.indptr)))
+            out = {"value": users_sub * iters_ref / float(m.group(2)), "unit": "updates/s", "cores": 1,
+                   "kind": "reference",
+                   "sample": "nickgreenquist/cu2rec mf_sequential.cu compiled unmodified (oracle/_ref/mf_cpu): first %d "
+                             "users (%d ratings) of the workload, %d iterations, f=%d; its own clock() timer, which "
+                             "includes its two loss evaluations; ~97%% of its time is per-update std::random_device + "
+                             "mt19937 construction (mf_sequential.cu:109-110)" % (n_users, sub_tr.nnz, iters_ref, f),
+                   "port": port}
+    if not out:
+        out = port
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", default="ml-20m", choices=["ml-100k", "ml-1m", "ml-20m", "netflix"])
+    ap.add_argument("--factors", type=int, default=100)
+    ap.add_argument("--mode", default="hogwild", choices=["hogwild", "serial"])
+    ap.add_argument("--sync-every", type=int, default=0, help="steps between item-factor all-reduces (0 = one epoch)")
+    ap.add_argument("--merge", default="mean", choices=["mean", "sum"])
+    ap.add_argument("--seed", type=int, default=20240917)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-samples", type=int, default=200)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the cu2rec_amd hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    import cu2rec_amd as cu
+    from cu2rec_amd.engine import DeviceRatings, Engine
+    from cu2rec_amd.parallel import ShardedSGD
+
+    train, test = load_dataset(args.workload, args.seed, rank, barrier)
+    f = args.factors
+    hyper = (0.01, 0.02, 0.02, 0.02, 0.02)  # preprocessing/create_config.py:25-32
+    users_active = int(np.count_nonzero(np.diff(train.indptr)))
+    sync_every = args.sync_every or max(1, int(round(train.nnz / max(users_active, 1))))
+
+    eng = Engine(train.rows, train.cols, f, train.global_bias, device=device)
+    d_train, d_test = DeviceRatings(train, device), DeviceRatings(test, device)
+    # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the global population
+    job = ShardedSGD(eng, d_train, user_offset=rank * train.rows, sync_every=sync_every, merge=args.merge)
+    mode = cu.SGD_HOGWILD if args.mode == "hogwild" else cu.SGD_SERIAL
+    rmse0 = job.loss(d_test)["rmse"]
+
+    it = 0
+    job.run(hyper, 42, it, args.warmup, mode)
+    it += args.warmup
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    job.run(hyper, 42, it, args.steps, mode)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    it += args.steps
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- SGD kernel duration: HIP events around single launches on the launch stream (untimed extra pass)
+    n_s = max(args.kernel_samples, 1)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_s)]
+    for a, b in evs:
+        a.record()
+        eng.sgd(d_train, hyper, 42, it, 1, mode, True, rank * train.rows)
+        b.record()
+        it += 1
+    torch.cuda.synchronize()
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kernel_ms_min = float(np.min([a.elapsed_time(b) for a, b in evs]))
+
+    final = job.loss(d_test)
+    bytes_per_update = 16 * f + 32
+    alg_bytes = users_active * bytes_per_update
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    value = world * users_active * args.steps / elapsed
+
+    if rank == 0:
+        line = {
+            "metric": "sgd_updates_per_sec", "value": value, "unit": "updates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s-shape synthetic ratings (users %d, items %d, train nnz %d, test nnz %d per GPU), "
+                                   "f=%d, lr .01, reg .02, mode %s" % (args.workload, train.rows, train.cols, train.nnz,
+                                                                         test.nnz, f, args.mode),
+                       "updates_per_step_per_gpu": users_active, "sync_every": sync_every if world > 1 else None,
+                       "merge": args.merge if world > 1 else None, "exchanges": job.exchanges},
+            "test_rmse": final["rmse"], "test_rmse_initial": rmse0, "iterations_run": it,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sgd_%s_kernel" % args.mode, "kernel_avg_us": 1e3 * kernel_ms,
+                         "kernel_min_us": 1e3 * kernel_ms_min, "algorithmic_bytes_per_launch": alg_bytes,
+                         "bytes_per_update": bytes_per_update},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(train, test, f, hyper)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+"""Loader for libcu2rec_amd.so (the C ABI in include/cu2rec_amd.h).
+
+The library is built in-tree by `make -C cu2rec_amd/csrc` (also by __graft_entry__.build()).
+There is no Python or CPU fallback for the hot path: if the shared object is missing, importing
+fails with instructions, and if no GPU is present the compute entry points return
+CU2REC_ENODEVICE, surfaced here as Cu2recError.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcu2rec_amd.so")
+
+
+class Cu2recError(RuntimeError):
+    """A non-zero cu2rec_status; the text is cu2rec_last_error() (the reference throws
+    std::runtime_error from CHECK_CUDA, util.h:27-34)."""
+
+    def __init__(self, status, message):
+        super().__init__("cu2rec_amd status %d: %s" % (status, message))
+        self.status = status
+
+
+class Config(C.Structure):
+    """config::Config (config.h:20-58); the first nine fields are the config file's fields."""
+    _fields_ = [("cur_iterations", C.c_int), ("total_iterations", C.c_int), ("n_factors", C.c_int),
+                ("learning_rate", C.c_float), ("seed", C.c_int), ("P_reg", C.c_float), ("Q_reg", C.c_float),
+                ("user_bias_reg", C.c_float), ("item_bias_reg", C.c_float), ("is_train", C.c_int),
+                ("n_threads", C.c_int), ("check_error", C.c_int), ("patience", C.c_float),
+                ("learning_rate_decay", C.c_float)]
+
+    def hyper(self):
+        return Hyper(self.learning_rate, self.P_reg, self.Q_reg, self.user_bias_reg, self.item_bias_reg)
+
+
+class Hyper(C.Structure):
+    _fields_ = [("learning_rate", C.c_float), ("P_reg", C.c_float), ("Q_reg", C.c_float),
+                ("user_bias_reg", C.c_float), ("item_bias_reg", C.c_float)]
+
+
+class TrainStats(C.Structure):
+    _fields_ = [("seconds_total", C.c_double), ("seconds_sgd", C.c_double), ("updates", C.c_double),
+                ("n_checks", C.c_int), ("last_train_mae", C.c_float), ("last_train_rmse", C.c_float),
+                ("last_test_mae", C.c_float), ("last_test_rmse", C.c_float)]
+
+
+_P = C.c_void_p
+_ip, _fp, _dp = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol include/cu2rec_amd.h declares
+SIGNATURES = {
+    "cu2rec_last_error": (C.c_char_p, []),
+    "cu2rec_version": (C.c_int, []),
+    "cu2rec_device_count": (C.c_int, []),
+    "cu2rec_set_device": (C.c_int, [C.c_int]),
+    "cu2rec_config_default": (C.c_int, [C.POINTER(Config)]),
+    "cu2rec_config_read": (C.c_int, [C.c_char_p, C.POINTER(Config)]),
+    "cu2rec_config_write": (C.c_int, [C.c_char_p, C.POINTER(Config)]),
+    "cu2rec_config_print": (C.c_int, [C.POINTER(Config)]),
+    "cu2rec_ratings_read_csv": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "cu2rec_ratings_info": (C.c_int, [_P, _ip, _ip, _ip, _fp]),
+    "cu2rec_ratings_view": (C.c_int, [_P, C.POINTER(_ip), C.POINTER(_ip), C.POINTER(_fp)]),
+    "cu2rec_ratings_free": (None, [_P]),
+    "cu2rec_csr_build": (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    "cu2rec_init_normal": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_float, C.c_float, C.c_int]),
+    "cu2rec_write_csv": (C.c_int, [C.c_char_p, _P, C.c_int, C.c_int]),
+    "cu2rec_write_component": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _P, C.c_int, C.c_int, C.c_int]),
+    "cu2rec_read_array": (C.c_int, [C.c_char_p, C.POINTER(_fp), _ip, _ip]),
+    "cu2rec_free": (None, [_P]),
+    "cu2rec_sampler_draw": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_uint64]),
+    "cu2rec_sampler_index": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
+    "cu2rec_sgd_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,
+                                    C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "cu2rec_loss_workspace_bytes": (C.c_size_t, []),
+    "cu2rec_loss": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P,
+                              _P, _dp, _dp, _fp, _fp, _P]),
+    "cu2rec_error_metrics": (C.c_int, [_P, C.c_int, _P, _fp, _fp, _P]),
+    "cu2rec_csr_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, C.POINTER(_P)]),
+    "cu2rec_csr_info": (C.c_int, [_P, _ip, _ip, _ip]),
+    "cu2rec_csr_device_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "cu2rec_csr_destroy": (None, [_P]),
+    "cu2rec_model_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_float, C.POINTER(_P)]),
+    "cu2rec_model_info": (C.c_int, [_P, _ip, _ip, _ip, _ip, _fp]),
+    "cu2rec_model_device_ptrs": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "cu2rec_model_download": (C.c_int, [_P, _P, _P, _P, _P]),
+    "cu2rec_model_destroy": (None, [_P]),
+    "cu2rec_model_sgd": (C.c_int, [_P, _P, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]),
+    "cu2rec_model_loss": (C.c_int, [_P, _P, _dp, _dp, _fp, _fp]),
+    "cu2rec_train": (C.c_int, [_P, _P, C.POINTER(Config), _P, C.c_int, C.c_int, _P, C.POINTER(TrainStats)]),
+    "cu2rec_shard_plan": (C.c_int, [C.c_int, C.c_int, _P]),
+    "cu2rec_csr_slice": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _ip, _ip]),
+    "cu2rec_items_delta_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "cu2rec_items_delta_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_float, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "cu2rec_amd: %s is missing. Build it with `make -C cu2rec_amd/csrc` (or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise Cu2recError(status, lib().cu2rec_last_error().decode(errors="replace"))

@@ -1,0 +1,63 @@
+// C++ convenience layer over the C ABI for host programs (bin/mf): RAII handles and status ->
+// exception, i.e. the error behaviour of the reference's CHECK_CUDA (util.h:27-34).
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/cu2rec_amd.h"
+
+namespace cu2rec {
+
+inline void check(int status) {
+    if (status != CU2REC_OK) throw std::runtime_error(cu2rec_last_error());
+}
+
+struct HostCsr {  // createSparseMatrix's host arrays (util.cu:152-166)
+    std::vector<int> indptr, indices;
+    std::vector<float> data;
+    int rows = 0, cols = 0, nnz = 0;
+    float global_bias = 0.f;
+};
+
+inline HostCsr load_ratings(const std::string &path) {  // readCSV + createSparseMatrix, mf.cu:43-44
+    cu2rec_ratings *r = nullptr;
+    check(cu2rec_ratings_read_csv(path.c_str(), &r));
+    HostCsr m;
+    try {
+        check(cu2rec_ratings_info(r, &m.nnz, &m.rows, &m.cols, &m.global_bias));
+        m.indptr.resize(static_cast<size_t>(m.rows) + 1);
+        m.indices.resize(m.nnz);
+        m.data.resize(m.nnz);
+        check(cu2rec_csr_build(r, m.rows, m.indptr.data(), m.indices.data(), m.data.data()));
+    } catch (...) {
+        cu2rec_ratings_free(r);
+        throw;
+    }
+    cu2rec_ratings_free(r);
+    return m;
+}
+
+struct CsrHandle {
+    cu2rec_csr *h = nullptr;
+    explicit CsrHandle(const HostCsr &m) {
+        check(cu2rec_csr_create(m.rows, m.cols, m.nnz, m.indptr.data(), m.indices.data(), m.data.data(), &h));
+    }
+    CsrHandle(const CsrHandle &) = delete;
+    CsrHandle &operator=(const CsrHandle &) = delete;
+    ~CsrHandle() { cu2rec_csr_destroy(h); }
+};
+
+struct ModelHandle {
+    cu2rec_model *h = nullptr;
+    ModelHandle(int rows, int cols, int f, float global_bias, const float *P = nullptr, const float *Q = nullptr,
+                const float *ub = nullptr, const float *ib = nullptr) {
+        check(cu2rec_model_create(rows, cols, f, P, Q, ub, ib, global_bias, &h));
+    }
+    ModelHandle(const ModelHandle &) = delete;
+    ModelHandle &operator=(const ModelHandle &) = delete;
+    ~ModelHandle() { cu2rec_model_destroy(h); }
+};
+
+}  // namespace cu2rec

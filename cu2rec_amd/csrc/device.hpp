@@ -1,0 +1,57 @@
+// Owned device objects and the C++ form of the raw hot-path entry points.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "hip_check.hpp"
+
+struct cu2rec_csr;
+struct cu2rec_model;
+
+namespace cu2rec {
+
+void sgd_update(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P, int ldp,
+                float *Q, int ldq, float *user_bias, float *item_bias, float global_bias, int n_factors,
+                const cu2rec_hyper &hyper, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
+                int user_offset, hipStream_t stream);
+
+void loss(const int *indptr, const int *indices, const float *data, int n_rows, int nnz, const float *P, int ldp,
+          const float *Q, int ldq, const float *user_bias, const float *item_bias, float global_bias, int n_factors,
+          float *errors_out, void *workspace, double *sum_abs, double *sum_sq, float *mae, float *rmse,
+          hipStream_t stream);
+
+void error_metrics(const float *errors, int n, void *workspace, float *mae, float *rmse, hipStream_t stream);
+
+// Device CSR in the reference's layout (matrix.h:11-19): int32 indptr / indices, float32 data.
+struct DeviceCsr {
+    DeviceCsr(int rows, int cols, int nnz, const int *h_indptr, const int *h_indices, const float *h_data);
+    DeviceBuffer<int> indptr, indices;
+    DeviceBuffer<float> data;
+    int rows, cols, nnz;
+    int max_item;
+    int users_with_ratings;
+};
+
+// P, Q, biases on the device with padded rows (see include/cu2rec_amd.h "Device data layout").
+struct DeviceModel {
+    DeviceModel(int rows, int cols, int n_factors, const float *P, const float *Q, const float *user_bias,
+                const float *item_bias, float global_bias);
+    void download(float *P, float *Q, float *user_bias, float *item_bias) const;
+    void sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t seed, uint64_t iter0, int n_iters, int mode,
+             int update_items, hipStream_t stream);
+    void loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq, float *mae, float *rmse,
+              hipStream_t stream) const;
+    DeviceBuffer<float> P, Q, user_bias, item_bias;
+    mutable DeviceBuffer<double> workspace;
+    int rows, cols, n_factors, ld;
+    float global_bias;
+};
+
+DeviceCsr &unwrap(cu2rec_csr *m);
+const DeviceCsr &unwrap(const cu2rec_csr *m);
+DeviceModel &unwrap(cu2rec_model *m);
+const DeviceModel &unwrap(const cu2rec_model *m);
+
+}  // namespace cu2rec

@@ -1,0 +1,380 @@
+// HIP kernels of the cu2rec hot path for gfx950 (MI355X / CDNA4).  Compiled with
+// -ffp-contract=off: every fused multiply-add below is an explicit __builtin_fmaf, so the
+// arithmetic is defined operation by operation and the CPU oracle can mirror it bit for bit.
+//
+// Geometry (all kernels): a 16-lane group -- one DPP row of a 64-wide wavefront -- owns one
+// user (SGD) or one chunk of ratings (loss).  Lane l of the group owns the float4 "slots"
+// l, l+16, l+32, ... of a factor row (row stride ld, a multiple of 4 floats, zero padded), so a
+// row of f <= 64 floats is ONE coalesced 16 B-per-lane access and f = 100 is two.  A dot
+// product is a per-lane fmaf chain over the lane's slots followed by a 4-step xor butterfly
+// inside the row, done with DPP modifiers (quad_perm / row_half_mirror / row_mirror): no LDS,
+// no ds_bpermute, and every lane of the group ends with the same bits.  Four users share a
+// wavefront; 256-thread blocks hold 16 users.
+//
+// What each kernel replaces in the reference (matrix_factorization/):
+//   sgd_hogwild_kernel / sgd_serial_kernel  sgd_update       sgd.cu:22-75   (+ initCurand :11-16: gone)
+//   loss_fused_kernel                       loss_kernel      loss.cu:19-35  + total_loss_kernel<B> :58-128 (x2)
+//   error_metrics_kernel                    total_loss_kernel<B>  loss.cu:58-128 on an explicit array
+//   items_delta_*                           (new: multi-GPU item-factor exchange)
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "sampler.hpp"
+
+namespace cu2rec {
+
+namespace {
+
+constexpr int kGroup = 16;                    // lanes per user: one DPP row
+constexpr int kBlock = 256;                   // threads per block: 4 wavefronts, 16 groups
+constexpr int kGroupsPerBlock = kBlock / kGroup;
+
+// ---- cross-lane sum inside a 16-lane row -------------------------------------------------
+template <int kCtrl>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, false));
+}
+
+// xor butterfly 1, 2, 4, 8.  After the quad steps every lane of a quad holds the quad's sum,
+// so mirroring inside 8 and then 16 lanes fetches exactly what the xor-4 / xor-8 partner holds.
+__device__ __forceinline__ float row_sum16(float v) {
+    v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = v + dpp_move<0x141>(v);  // row_half_mirror
+    v = v + dpp_move<0x140>(v);  // row_mirror
+    return v;
+}
+
+// ---- factor rows -------------------------------------------------------------------------
+template <int J>
+struct Row {
+    float4 v[J];
+};
+
+template <int J>
+__device__ __forceinline__ Row<J> load_row(const float *__restrict__ base, size_t row, int ld, int nslots, int lane) {
+    const float4 *p = reinterpret_cast<const float4 *>(base + row * static_cast<size_t>(ld));
+    Row<J> r;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int slot = lane + kGroup * j;
+        r.v[j] = slot < nslots ? p[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return r;
+}
+
+template <int J>
+__device__ __forceinline__ void store_row(float *__restrict__ base, size_t row, int ld, int nslots, int lane,
+                                          const Row<J> &r) {
+    float4 *p = reinterpret_cast<float4 *>(base + row * static_cast<size_t>(ld));
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int slot = lane + kGroup * j;
+        if (slot < nslots) p[slot] = r.v[j];
+    }
+}
+
+// util.cu:199-204 get_prediction, in the group's order: per-lane fmaf chain in slot order,
+// butterfly, then ((gb + ub) + ib) + dot.
+template <int J>
+__device__ __forceinline__ float predict(const Row<J> &p, const Row<J> &q, float ub, float ib, float gb) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        acc = __builtin_fmaf(q.v[j].x, p.v[j].x, acc);
+        acc = __builtin_fmaf(q.v[j].y, p.v[j].y, acc);
+        acc = __builtin_fmaf(q.v[j].z, p.v[j].z, acc);
+        acc = __builtin_fmaf(q.v[j].w, p.v[j].w, acc);
+    }
+    const float dot = row_sum16(acc);
+    return ((gb + ub) + ib) + dot;
+}
+
+// mf_sequential.cu:133-136 on one float: new = old + lr * (err * other_old - reg * old)
+__device__ __forceinline__ float step(float old, float other_old, float err, float lr, float reg) {
+    return old + lr * (err * other_old - reg * old);
+}
+
+template <int J>
+__device__ __forceinline__ void rank1_update(Row<J> &p, Row<J> &q, float err, const SgdHyper &h) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const float4 po = p.v[j], qo = q.v[j];
+        p.v[j].x = step(po.x, qo.x, err, h.lr, h.p_reg);
+        p.v[j].y = step(po.y, qo.y, err, h.lr, h.p_reg);
+        p.v[j].z = step(po.z, qo.z, err, h.lr, h.p_reg);
+        p.v[j].w = step(po.w, qo.w, err, h.lr, h.p_reg);
+        q.v[j].x = step(qo.x, po.x, err, h.lr, h.q_reg);
+        q.v[j].y = step(qo.y, po.y, err, h.lr, h.q_reg);
+        q.v[j].z = step(qo.z, po.z, err, h.lr, h.q_reg);
+        q.v[j].w = step(qo.w, po.w, err, h.lr, h.q_reg);
+    }
+}
+
+// One SGD update of user x at iteration `it` (sgd.cu:27-73 / mf_sequential.cu:104-142), p and
+// the user bias live in registers; the item row is read, updated and written back in place.
+template <int J>
+__device__ __forceinline__ void sgd_one(const SgdArgs &a, int x, int low, int high, uint64_t it, int lane,
+                                        Row<J> &p, float &ub) {
+    const int y_i = sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + x), it, low, high);  // sgd.cu:36-37
+    const int y = a.indices[y_i];
+    const float rating = a.data[y_i];
+    Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
+    const float ib = a.item_bias[y];
+    const float err = rating - predict<J>(p, q, ub, ib, a.global_bias);  // sgd.cu:45
+    rank1_update<J>(p, q, err, a.h);                                      // sgd.cu:53-64
+    if (a.update_items) {                                                 // config::is_train, sgd.cu:61,70
+        store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
+        if (lane == 0) a.item_bias[y] = ib + a.h.lr * (err - a.h.ib_reg * ib);  // sgd.cu:71
+    }
+    ub = ub + a.h.lr * (err - a.h.ub_reg * ub);  // sgd.cu:67
+}
+
+// ---- SGD, Hogwild: every user of the iteration in flight ------------------------------------
+template <int J>
+__global__ __launch_bounds__(kBlock) void sgd_hogwild_kernel(SgdArgs a) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
+    const int n_groups = gridDim.x * kGroupsPerBlock;
+    for (int x = group; x < a.n_rows; x += n_groups) {
+        const int low = a.indptr[x], high = a.indptr[x + 1];
+        if (low == high) continue;  // sgd.cu:34: users without ratings are skipped
+        Row<J> p = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+        float ub = a.user_bias[x];
+        for (int k = 0; k < a.iters; ++k) sgd_one<J>(a, x, low, high, a.iter0 + static_cast<uint64_t>(k), lane, p, ub);
+        store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
+        if (lane == 0) a.user_bias[x] = ub;
+    }
+}
+
+// ---- SGD, serial order: one group walks the users ascending (mf_sequential.cu:102-143) -----
+template <int J>
+__global__ __launch_bounds__(64) void sgd_serial_kernel(SgdArgs a) {
+    if (threadIdx.x >= kGroup || blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    for (int k = 0; k < a.iters; ++k) {
+        for (int x = 0; x < a.n_rows; ++x) {
+            const int low = a.indptr[x], high = a.indptr[x + 1];
+            if (low == high) continue;
+            Row<J> p = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+            float ub = a.user_bias[x];
+            sgd_one<J>(a, x, low, high, a.iter0 + static_cast<uint64_t>(k), lane, p, ub);
+            store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
+            if (lane == 0) a.user_bias[x] = ub;
+            __threadfence();  // the next user may read the item row this one just wrote
+        }
+    }
+}
+
+// ---- fused loss: residual + sum|e| + sum e^2 in one pass ---------------------------------------
+constexpr int kLossChunk = 64;  // ratings per group per step
+
+// largest u in [0, n_rows) with indptr[u] <= k (k < nnz guarantees indptr[u+1] > k after skipping empties)
+__device__ __forceinline__ int user_of_rating(const int *__restrict__ indptr, int n_rows, int k) {
+    int lo = 0, hi = n_rows;  // invariant: indptr[lo] <= k < indptr[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (indptr[mid] <= k) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <int J>
+__global__ __launch_bounds__(kBlock) void loss_fused_kernel(LossArgs a) {
+    __shared__ double s_abs[kGroupsPerBlock], s_sq[kGroupsPerBlock];
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group_in_block = threadIdx.x / kGroup;
+    const int group = blockIdx.x * kGroupsPerBlock + group_in_block;
+    const int n_groups = gridDim.x * kGroupsPerBlock;
+    const int n_chunks = (a.nnz + kLossChunk - 1) / kLossChunk;
+    double sum_abs = 0.0, sum_sq = 0.0;
+    for (int chunk = group; chunk < n_chunks; chunk += n_groups) {
+        const int k0 = chunk * kLossChunk;
+        const int k1 = min(a.nnz, k0 + kLossChunk);
+        int u = user_of_rating(a.indptr, a.n_rows, k0);
+        int row_end = a.indptr[u + 1];
+        Row<J> p = load_row<J>(a.P, static_cast<size_t>(u), a.ldp, a.nslots, lane);
+        float ub = a.user_bias[u];
+        for (int kb = k0; kb < k1; kb += kGroup) {
+            // one coalesced 64 B read of 16 item ids and 16 ratings per group (loss.cu:29-31 walks them one by one)
+            const int mine = kb + lane;
+            const int my_item = mine < k1 ? a.indices[mine] : 0;
+            const float my_rating = mine < k1 ? a.data[mine] : 0.f;
+            const int n_here = min(kGroup, k1 - kb);
+            for (int t = 0; t < n_here; ++t) {
+                const int k = kb + t;
+                while (k >= row_end) {  // next user (users without ratings are stepped over)
+                    ++u;
+                    row_end = a.indptr[u + 1];
+                    if (k < row_end) {
+                        p = load_row<J>(a.P, static_cast<size_t>(u), a.ldp, a.nslots, lane);
+                        ub = a.user_bias[u];
+                    }
+                }
+                const int item = __shfl(my_item, t, kGroup);
+                const float rating = __shfl(my_rating, t, kGroup);
+                const Row<J> q = load_row<J>(a.Q, static_cast<size_t>(item), a.ldq, a.nslots, lane);
+                const float e = rating - predict<J>(p, q, ub, a.item_bias[item], a.global_bias);  // loss.cu:31
+                if (a.errors_out != nullptr && lane == 0) a.errors_out[k] = e;
+                sum_abs += static_cast<double>(fabsf(e));                    // loss.cu:70 (MAE pass)
+                sum_sq += static_cast<double>(e) * static_cast<double>(e);   // loss.cu:70 (RMSE pass, pow(e,2) in double)
+            }
+        }
+    }
+    // every lane of a group carries the same sums; lane 0 publishes, thread 0 adds the 16 groups in order
+    if (lane == 0) {
+        s_abs[group_in_block] = sum_abs;
+        s_sq[group_in_block] = sum_sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, ts = 0.0;
+        for (int g = 0; g < kGroupsPerBlock; ++g) {
+            ta += s_abs[g];
+            ts += s_sq[g];
+        }
+        a.partials[2 * blockIdx.x] = ta;
+        a.partials[2 * blockIdx.x + 1] = ts;
+    }
+}
+
+// ---- total loss on an explicit residual array (loss.cu:58-128, both error types at once) ----
+__global__ __launch_bounds__(kBlock) void error_metrics_kernel(const float *__restrict__ errors, int n,
+                                                               double *__restrict__ partials) {
+    __shared__ double s_abs[kBlock], s_sq[kBlock];
+    double sa = 0.0, ss = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const float e = errors[i];
+        sa += static_cast<double>(fabsf(e));
+        ss += static_cast<double>(e) * static_cast<double>(e);
+    }
+    s_abs[threadIdx.x] = sa;
+    s_sq[threadIdx.x] = ss;
+    __syncthreads();
+    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {  // every step guarded and barriered (cf. loss.cu:103-124)
+        if (static_cast<int>(threadIdx.x) < stride) {
+            s_abs[threadIdx.x] += s_abs[threadIdx.x + stride];
+            s_sq[threadIdx.x] += s_sq[threadIdx.x + stride];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = s_abs[0];
+        partials[2 * blockIdx.x + 1] = s_sq[0];
+    }
+}
+
+// ---- multi-GPU item-factor exchange helpers -------------------------------------------------
+__global__ __launch_bounds__(kBlock) void items_delta_pack_kernel(const float *__restrict__ Q,
+                                                                  const float *__restrict__ ib,
+                                                                  const float *__restrict__ Q_base,
+                                                                  const float *__restrict__ ib_base, size_t nq,
+                                                                  int n_cols, float *__restrict__ buf) {
+    const size_t total = nq + static_cast<size_t>(n_cols);
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kBlock)
+        buf[i] = i < nq ? Q[i] - Q_base[i] : ib[i - nq] - ib_base[i - nq];
+}
+
+__global__ __launch_bounds__(kBlock) void items_delta_apply_kernel(float *__restrict__ Q, float *__restrict__ ib,
+                                                                   float *__restrict__ Q_base,
+                                                                   float *__restrict__ ib_base, size_t nq, int n_cols,
+                                                                   const float *__restrict__ buf, float scale) {
+    const size_t total = nq + static_cast<size_t>(n_cols);
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        if (i < nq) {
+            const float v = Q_base[i] + scale * buf[i];
+            Q[i] = v;
+            Q_base[i] = v;
+        } else {
+            const float v = ib_base[i - nq] + scale * buf[i];
+            ib[i - nq] = v;
+            ib_base[i - nq] = v;
+        }
+    }
+}
+
+inline int blocks_for(size_t work_items, size_t per_block, int cap) {
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > static_cast<size_t>(cap)) b = static_cast<size_t>(cap);
+    return static_cast<int>(b);
+}
+
+template <int J>
+void launch_sgd_j(const SgdArgs &a, int mode, hipStream_t stream) {
+    if (mode == CU2REC_SGD_SERIAL) {
+        hipLaunchKernelGGL(sgd_serial_kernel<J>, dim3(1), dim3(64), 0, stream, a);
+    } else {
+        // one group per user; the dispatcher keeps the CUs fed with far more than 256 blocks
+        const int blocks = blocks_for(static_cast<size_t>(a.n_rows), kGroupsPerBlock, 1 << 20);
+        hipLaunchKernelGGL(sgd_hogwild_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a);
+    }
+}
+
+template <int J>
+void launch_loss_j(const LossArgs &a, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(loss_fused_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a);
+}
+
+}  // namespace
+
+int slots_per_lane(int nslots) { return (nslots + kGroup - 1) / kGroup; }
+
+void launch_sgd(const SgdArgs &a, int mode, hipStream_t stream) {
+    switch (slots_per_lane(a.nslots)) {
+        case 1: launch_sgd_j<1>(a, mode, stream); break;
+        case 2: launch_sgd_j<2>(a, mode, stream); break;
+        case 3: launch_sgd_j<3>(a, mode, stream); break;
+        case 4: launch_sgd_j<4>(a, mode, stream); break;
+        case 5: launch_sgd_j<5>(a, mode, stream); break;
+        case 6: launch_sgd_j<6>(a, mode, stream); break;
+        case 7: launch_sgd_j<7>(a, mode, stream); break;
+        case 8: launch_sgd_j<8>(a, mode, stream); break;
+        default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
+    }
+}
+
+int loss_blocks(int nnz) {
+    const size_t chunks = (static_cast<size_t>(nnz) + kLossChunk - 1) / kLossChunk;
+    return blocks_for(chunks, kGroupsPerBlock, kMaxPartialBlocks);
+}
+
+void launch_loss(const LossArgs &a, int blocks, hipStream_t stream) {
+    switch (slots_per_lane(a.nslots)) {
+        case 1: launch_loss_j<1>(a, blocks, stream); break;
+        case 2: launch_loss_j<2>(a, blocks, stream); break;
+        case 3: launch_loss_j<3>(a, blocks, stream); break;
+        case 4: launch_loss_j<4>(a, blocks, stream); break;
+        case 5: launch_loss_j<5>(a, blocks, stream); break;
+        case 6: launch_loss_j<6>(a, blocks, stream); break;
+        case 7: launch_loss_j<7>(a, blocks, stream); break;
+        case 8: launch_loss_j<8>(a, blocks, stream); break;
+        default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
+    }
+}
+
+int error_metrics_blocks(int n) { return blocks_for(static_cast<size_t>(n), kBlock * 4, kMaxPartialBlocks); }
+
+void launch_error_metrics(const float *errors, int n, double *partials, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(error_metrics_kernel, dim3(blocks), dim3(kBlock), 0, stream, errors, n, partials);
+}
+
+void launch_items_delta_pack(const float *Q, const float *ib, const float *Q_base, const float *ib_base, int n_cols,
+                             int ldq, float *buf, hipStream_t stream) {
+    const size_t nq = static_cast<size_t>(n_cols) * ldq;
+    const int blocks = blocks_for(nq + n_cols, kBlock * 4, 4096);
+    hipLaunchKernelGGL(items_delta_pack_kernel, dim3(blocks), dim3(kBlock), 0, stream, Q, ib, Q_base, ib_base, nq,
+                       n_cols, buf);
+}
+
+void launch_items_delta_apply(float *Q, float *ib, float *Q_base, float *ib_base, int n_cols, int ldq,
+                              const float *buf, float scale, hipStream_t stream) {
+    const size_t nq = static_cast<size_t>(n_cols) * ldq;
+    const int blocks = blocks_for(nq + n_cols, kBlock * 4, 4096);
+    hipLaunchKernelGGL(items_delta_apply_kernel, dim3(blocks), dim3(kBlock), 0, stream, Q, ib, Q_base, ib_base, nq,
+                       n_cols, buf, scale);
+}
+
+}  // namespace cu2rec

@@ -1,0 +1,67 @@
+// Launch interface between the host code and kernels.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "common.hpp"
+
+namespace cu2rec {
+
+// Hyper-parameters travel by value in the kernel argument block (SGPRs on CDNA) instead of the
+// reference's __constant__ symbols (config.h:9-18, config.cu:24-35).
+struct SgdHyper {
+    float lr, p_reg, q_reg, ub_reg, ib_reg;
+};
+
+struct SgdArgs {
+    const int *indptr;    // [n_rows + 1]
+    const int *indices;   // [nnz]
+    const float *data;    // [nnz]
+    float *P;             // [n_rows x ldp]
+    float *Q;             // [n_cols x ldq]
+    float *user_bias;     // [n_rows]
+    float *item_bias;     // [n_cols]
+    int n_rows;
+    int ldp, ldq;         // row strides in floats, multiples of 4
+    int nslots;           // float4 slots per row = ceil(n_factors / 4)
+    float global_bias;
+    SgdHyper h;
+    uint64_t seed;
+    uint64_t iter0;       // global iteration number of the first update
+    int iters;            // updates per user in this launch
+    int update_items;     // 0: Q and item_bias frozen (is_train == false)
+    int user_offset;      // global id of row 0 (user-sharded runs); enters the sampler only
+};
+
+struct LossArgs {
+    const int *indptr;
+    const int *indices;
+    const float *data;
+    const float *P;
+    const float *Q;
+    const float *user_bias;
+    const float *item_bias;
+    int n_rows, nnz;
+    int ldp, ldq, nslots;
+    float global_bias;
+    float *errors_out;    // [nnz] or nullptr
+    double *partials;     // [2 * blocks]: per block {sum |e|, sum e^2}
+};
+
+constexpr int kMaxPartialBlocks = 4096;
+
+int slots_per_lane(int nslots);
+void launch_sgd(const SgdArgs &args, int mode, hipStream_t stream);
+int loss_blocks(int nnz);
+void launch_loss(const LossArgs &args, int blocks, hipStream_t stream);
+int error_metrics_blocks(int n);
+void launch_error_metrics(const float *errors, int n, double *partials, int blocks, hipStream_t stream);
+void launch_items_delta_pack(const float *Q, const float *ib, const float *Q_base, const float *ib_base, int n_cols,
+                             int ldq, float *buf, hipStream_t stream);
+void launch_items_delta_apply(float *Q, float *ib, float *Q_base, float *ib_base, int n_cols, int ldq,
+                              const float *buf, float scale, hipStream_t stream);
+
+}  // namespace cu2rec

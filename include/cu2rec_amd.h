@@ -1,0 +1,244 @@
+/*
+ * cu2rec_amd.h -- C ABI of the MI355X-native cu2rec hot path (libcu2rec_amd.so).
+ *
+ * Plain C: pointers, sizes, PODs.  No torch / HIP types in any signature (streams travel as
+ * void*, device buffers as raw pointers).  Every entry point returns CU2REC_OK (0) or a
+ * negative cu2rec_status; cu2rec_last_error() gives the message of the calling thread's last
+ * failure.  The reference reports failures by throwing std::runtime_error from CHECK_CUDA
+ * (util.h:27-34) or by printing to stderr and returning an empty result (util.cu:41-44); the
+ * C++ wrappers in cu2rec_amd/csrc/cu2rec.hpp turn a non-zero status back into that exception.
+ *
+ * Each declaration names the reference interface it replaces
+ * (paths relative to nickgreenquist/cu2rec matrix_factorization/).
+ *
+ * Device data layout ("padded rows"): dense factor matrices are row-major float32 with a row
+ * stride `ld` that is a multiple of 4 floats (16 B) and >= n_factors; the padding floats must
+ * be zero (they then stay zero under every kernel here).  ld == n_factors is the reference's
+ * own layout (matrix.h:21-28) whenever n_factors % 4 == 0.  CSR is exactly the reference's:
+ * int32 indptr[rows+1], int32 indices[nnz], float32 data[nnz] (matrix.h:11-19).
+ */
+#ifndef CU2REC_AMD_H
+#define CU2REC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CU2REC_AMD_VERSION 100 /* 0.1.0 */
+
+typedef enum cu2rec_status {
+    CU2REC_OK = 0,
+    CU2REC_EINVAL = -1,   /* bad argument (null pointer, bad shape, unsorted ratings, ...) */
+    CU2REC_EIO = -2,      /* file cannot be opened / parsed */
+    CU2REC_EHIP = -3,     /* a HIP runtime call failed (the reference's CHECK_CUDA throw) */
+    CU2REC_ENODEVICE = -4,/* no usable GPU: the hot path never falls back to the CPU */
+    CU2REC_ENOMEM = -5,
+    CU2REC_EUNSUPPORTED = -6 /* e.g. n_factors above the compiled kernel range */
+} cu2rec_status;
+
+const char *cu2rec_last_error(void);
+int cu2rec_version(void);
+/* number of visible HIP devices, 0 if none (never fails) */
+int cu2rec_device_count(void);
+/* select the device used by subsequent calls of this thread (hipSetDevice) */
+int cu2rec_set_device(int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Config -- replaces config::Config (config.h:20-58) and its file format (config.cu:7-22).
+ * The first nine fields are the file's nine whitespace separated fields, in file order.
+ * The `__constant__` mirror (config.h:9-18, config.cu:24-48) has no equivalent: hyper-parameters
+ * are passed to kernels by value (cu2rec_hyper below).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cu2rec_config {
+    int cur_iterations;        /* config.h:23 */
+    int total_iterations;      /* config.h:25  (default 5000) */
+    int n_factors;             /* config.h:27  (default 50) */
+    float learning_rate;       /* config.h:29  (default 0.01) */
+    int seed;                  /* config.h:31  (default 42): sampler seed, training.cu:88 */
+    float P_reg;               /* config.h:33  (default 0.02) */
+    float Q_reg;               /* config.h:35 */
+    float user_bias_reg;       /* config.h:37 */
+    float item_bias_reg;       /* config.h:39 */
+    int is_train;              /* config.h:41: 0 freezes Q and item_bias (honoured here; the
+                                  reference never uploads it, config.cu:24-35) */
+    int n_threads;             /* config.h:43 (default 32): kept for schema compatibility and
+                                  printed; launch geometry is chosen by the library */
+    int check_error;           /* config.h:45 (default 500) */
+    float patience;            /* config.h:48 (default 2) */
+    float learning_rate_decay; /* config.h:51 (default 0.2) */
+} cu2rec_config;
+
+int cu2rec_config_default(cu2rec_config *cfg);
+int cu2rec_config_read(const char *path, cu2rec_config *cfg);        /* Config::read_config  config.cu:7-13 */
+int cu2rec_config_write(const char *path, const cu2rec_config *cfg); /* Config::write_config config.cu:15-22 */
+int cu2rec_config_print(const cu2rec_config *cfg);                   /* Config::print_config config.cu:50-64 (stdout) */
+
+/* ------------------------------------------------------------------------------------------
+ * Ratings file -> host CSR.  Replaces readCSV (util.cu:17-45) and the host half of
+ * createSparseMatrix (util.cu:152-179).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cu2rec_ratings cu2rec_ratings; /* opaque, host memory */
+
+/* "userId,itemId,rating" with one header line; ids 1-based, converted to 0-based.  rows/cols
+ * = max id seen, global_bias = float(double sum / n).  A file that cannot be opened is
+ * CU2REC_EIO (the reference prints "ERROR: The file isnt open." and returns nothing). */
+int cu2rec_ratings_read_csv(const char *path, cu2rec_ratings **out);
+int cu2rec_ratings_info(const cu2rec_ratings *r, int *n, int *rows, int *cols, float *global_bias);
+/* raw COO views (length n), valid until cu2rec_ratings_free */
+int cu2rec_ratings_view(const cu2rec_ratings *r, const int **user, const int **item, const float **rating);
+void cu2rec_ratings_free(cu2rec_ratings *r);
+/* Build the CSR into caller memory: indptr[rows+1], indices[n], data[n].  Users without
+ * ratings get repeated pointers (tests/test_util.cu:146-189).  Ratings must be grouped by
+ * ascending user (CU2REC_EINVAL otherwise -- the reference would not terminate); item order
+ * inside a user is kept as in the file.  rows must be >= the largest user id. */
+int cu2rec_csr_build(const cu2rec_ratings *r, int rows, int *indptr, int *indices, float *data);
+
+/* initialize_normal_array (util.cu:124-144): std::mt19937(seed) +
+ * std::normal_distribution<float>(mean, stddev / n_factors), sequential fill. */
+int cu2rec_init_normal(float *out, size_t size, int n_factors, float mean, float stddev, int seed);
+
+/* writeCSV / writeToFile (util.cu:86-103): "%f" comma joined rows;
+ * file name <parent_dir>/<base>_f<factors>_<component>.csv */
+int cu2rec_write_csv(const char *path, const float *data, int rows, int cols);
+int cu2rec_write_component(const char *parent_dir, const char *base, const char *component, const float *data,
+                           int rows, int cols, int factors);
+/* read_array (util.cu:52-81): comma separated float rows; *out is malloc'ed -> cu2rec_free */
+int cu2rec_read_array(const char *path, float **out, int *rows, int *cols);
+void cu2rec_free(void *p);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampler.  Replaces initCurand + curand_uniform (sgd.cu:11-16,36-37).  Counter based, no
+ * state array, no init kernel: the draw of (user, iteration) is the first word of
+ * rocRAND's Philox4x32-10 stream rocrand_init(seed, subsequence=user, offset=4*iteration),
+ * mapped to (0,1] as rocrand_uniform does, then y_i = ceil(u * n) - 1 + low  (sgd.cu:37).
+ * Host copy of the device function, for tests and for callers that need the schedule.
+ * ---------------------------------------------------------------------------------------- */
+uint32_t cu2rec_sampler_draw(uint64_t seed, uint64_t user, uint64_t iteration);
+int cu2rec_sampler_index(uint64_t seed, uint64_t user, uint64_t iteration, int low, int high);
+
+/* ------------------------------------------------------------------------------------------
+ * Hot path on raw device pointers.  These are what a maintainer binds when the buffers
+ * already live on the GPU (the reference's kernel-level interface, sgd.h:12-16, loss.h:18-24).
+ * All pointers are device pointers on the current device unless marked host.  `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous unless they
+ * return host results.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cu2rec_hyper { /* the kernel-visible subset of config (config.h:9-18) */
+    float learning_rate, P_reg, Q_reg, user_bias_reg, item_bias_reg;
+} cu2rec_hyper;
+
+typedef enum cu2rec_sgd_mode {
+    /* One 16-lane group per user, all users of an iteration in flight at once; P, user_bias
+     * updated in place by their owner, Q / item_bias rows updated in place with plain stores
+     * (Hogwild: concurrent updates of one item overwrite each other, sgd.cu:18-21).  The
+     * throughput path. */
+    CU2REC_SGD_HOGWILD = 0,
+    /* One group walks the users in ascending order: mf_sequential.cu:102-143 exactly
+     * (in-place Gauss-Seidel).  Bit-identical to the CPU oracle in its TREE16 dot order.
+     * For parity tests; orders of magnitude slower. */
+    CU2REC_SGD_SERIAL = 1
+} cu2rec_sgd_mode;
+
+/* Replaces sgd_update (sgd.cu:22-75) + the per-iteration launch loop of train()
+ * (training.cu:107-115): runs iterations [iter0, iter0 + n_iters), one update per user with
+ * at least one rating per iteration.  update_items == 0 is is_train == false.
+ * user_offset: global id of row 0 (0 unless the rows are one shard of a user-sharded set); it only
+ * enters the sampler, so a shard draws exactly what the unsharded run draws for the same users. */
+int cu2rec_sgd_update(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols,
+                      float *P, int ldp, float *Q, int ldq, float *user_bias, float *item_bias, float global_bias,
+                      int n_factors, const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters,
+                      int mode, int update_items, int user_offset, void *stream);
+
+/* Replaces calculate_loss_gpu + get_error_metrics_gpu (loss.cu:19-49,150-200) in ONE pass:
+ * residual e = r - (gb + ub + ib + p.q) per rating, sum |e| and sum e^2 accumulated in
+ * double, MAE = S1/n, RMSE = sqrt(S2/n) returned as float (loss.cu:185-190).
+ * errors_out (device, nnz floats) may be NULL; when given it receives the residuals like the
+ * reference's error_d array (loss.cu:31).  workspace: device memory of at least
+ * cu2rec_loss_workspace_bytes() bytes.  Synchronises `stream` (host results). */
+size_t cu2rec_loss_workspace_bytes(void);
+int cu2rec_loss(const int *indptr, const int *indices, const float *data, int n_rows, int nnz,
+                const float *P, int ldp, const float *Q, int ldq, const float *user_bias, const float *item_bias,
+                float global_bias, int n_factors, float *errors_out, void *workspace, double *sum_abs,
+                double *sum_sq, float *mae, float *rmse, void *stream);
+
+/* Replaces total_loss_kernel<B> + calculate_error_metric_gpu x2 (loss.cu:58-128,150-200) on an
+ * explicit device array of residuals (tests/test_loss.cu:106-147). */
+int cu2rec_error_metrics(const float *errors, int n, void *workspace, float *mae, float *rmse, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Owned device objects.  Replace CudaCSRMatrix / CudaDenseMatrix (matrix.h:11-28,
+ * matrix.cu:12-46): constructor = allocate + H2D, destroy = free, download = to_host.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cu2rec_csr cu2rec_csr;     /* device CSR */
+typedef struct cu2rec_model cu2rec_model; /* device P, Q, user_bias, item_bias + global_bias */
+
+int cu2rec_csr_create(int rows, int cols, int nnz, const int *indptr, const int *indices, const float *data,
+                      cu2rec_csr **out); /* host arrays in, CudaCSRMatrix ctor matrix.cu:28-40 */
+int cu2rec_csr_info(const cu2rec_csr *m, int *rows, int *cols, int *nnz);
+int cu2rec_csr_device_ptrs(const cu2rec_csr *m, const int **indptr, const int **indices, const float **data);
+void cu2rec_csr_destroy(cu2rec_csr *m);
+
+/* Host arrays are dense (row stride n_factors), the reference's layout; any of P/Q/biases may
+ * be NULL = initialise like the reference: initialize_normal_array(..., seed 42)
+ * (training.cu:28,54,212-213). */
+int cu2rec_model_create(int rows, int cols, int n_factors, const float *P, const float *Q, const float *user_bias,
+                        const float *item_bias, float global_bias, cu2rec_model **out);
+int cu2rec_model_info(const cu2rec_model *m, int *rows, int *cols, int *n_factors, int *ld, float *global_bias);
+int cu2rec_model_device_ptrs(const cu2rec_model *m, float **P, float **Q, float **user_bias, float **item_bias);
+/* dense host arrays out (any may be NULL): CudaDenseMatrix::to_host + bias copies, training.cu:180-185 */
+int cu2rec_model_download(const cu2rec_model *m, float *P, float *Q, float *user_bias, float *item_bias);
+void cu2rec_model_destroy(cu2rec_model *m);
+
+int cu2rec_model_sgd(cu2rec_model *m, const cu2rec_csr *train, const cu2rec_hyper *hyper, uint64_t seed,
+                     uint64_t iter0, int n_iters, int mode, int update_items);
+int cu2rec_model_loss(const cu2rec_model *m, const cu2rec_csr *ratings, double *sum_abs, double *sum_sq,
+                      float *mae, float *rmse);
+
+/* ------------------------------------------------------------------------------------------
+ * train() -- replaces both overloads of train (training.h:12-15, training.cu:21-217):
+ * total_iterations iterations; loss on train and test when i == 0, (i+1) % check_error == 0
+ * or last (training.cu:118) printed as "TRAIN: Iteration %d GPU MAE: %f RMSE: %f" / "TEST: ..."
+ * (training.cu:135,137) when `verbose`; patience / learning-rate decay on the test RMSE
+ * (training.cu:101-103,146-155, "New Learning Rate" line); "Time taken for %d of iterations
+ * is %lf" (training.cu:177).  cfg->learning_rate and cfg->cur_iterations are updated as the
+ * reference does (training.cu:152,170).  losses (host, total_iterations floats, may be NULL):
+ * losses[i] = test RMSE at the checked iterations (training.cu:158), NaN elsewhere.
+ * The model is updated in place; download it afterwards.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cu2rec_train_stats {
+    double seconds_total;  /* wall time of the loop, loss checks included (training.cu:106,172-177) */
+    double seconds_sgd;    /* GPU time of the SGD launches only (HIP events) */
+    double updates;        /* users-with-ratings x iterations */
+    int n_checks;
+    float last_train_mae, last_train_rmse, last_test_mae, last_test_rmse;
+} cu2rec_train_stats;
+
+int cu2rec_train(const cu2rec_csr *train, const cu2rec_csr *test, cu2rec_config *cfg, cu2rec_model *model,
+                 int mode, int verbose, float *losses, cu2rec_train_stats *stats);
+
+/* ------------------------------------------------------------------------------------------
+ * Sharding by user (multi-GPU; the reference is single device).  Host-side planner:
+ * user_begin[nranks+1] with contiguous ranges of (almost) equal user count; work per SGD
+ * iteration is one update per user.
+ * ---------------------------------------------------------------------------------------- */
+int cu2rec_shard_plan(int rows, int nranks, int *user_begin);
+/* Slice a host CSR to users [u0,u1): indptr_out[u1-u0+1] rebased to 0; returns the slice's
+ * nnz in *nnz_out and the offset of its first rating in *offset_out (indices/data slices are
+ * then plain sub-arrays). */
+int cu2rec_csr_slice(const int *indptr, int rows, int u0, int u1, int *indptr_out, int *offset_out, int *nnz_out);
+/* Device helpers for the item-factor exchange (one fused buffer of n_cols*(ld+1) floats):
+ *   pack:   buf = [Q - Q_base | item_bias - item_bias_base]
+ *   apply:  Q = Q_base + scale * buf_Q ; item_bias likewise ; then Q_base = Q (new snapshot)
+ * between them the caller all-reduces `buf` (RCCL via torch.distributed or ncclAllReduce). */
+int cu2rec_items_delta_pack(const float *Q, const float *item_bias, const float *Q_base, const float *ib_base,
+                            int n_cols, int ldq, float *buf, void *stream);
+int cu2rec_items_delta_apply(float *Q, float *item_bias, float *Q_base, float *ib_base, int n_cols, int ldq,
+                             const float *buf, float scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CU2REC_AMD_H */

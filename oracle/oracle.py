@@ -178,6 +178,19 @@ def sgd_iterations(csr, P, Q, ub, ib, global_bias, hyper, seed, iter0, n_iters, 
                              1 if update_items else 0)
 
 
+def sgd_one(csr, x, P, Q, ub, ib, global_bias, hyper, seed, it, dot_order=DOT_SEQ, update_items=True):
+    """One update of user x at iteration `it`, in place (the loop body, mf_sequential.cu:104-142)."""
+    L = lib()
+    if L.orc_sgd_one.argtypes is None:
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.orc_sgd_one.restype = None
+        L.orc_sgd_one.argtypes = [ip, ip, fp, C.c_int, fp, fp, fp, fp, C.c_float, C.POINTER(Hyper), C.c_int,
+                                  C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+    h = Hyper(*[float(v) for v in hyper])
+    L.orc_sgd_one(_i(csr.indptr), _i(csr.indices), _f(csr.data), int(x), _f(P), _f(Q), _f(ub), _f(ib),
+                  float(global_bias), C.byref(h), P.shape[1], seed, it, dot_order, 1 if update_items else 0)
+
+
 def loss(csr, P, Q, ub, ib, global_bias, dot_order=DOT_SEQ, acc=ACC_F64, want_errors=False, rows=None):
     f = P.shape[1]
     rows = csr.rows if rows is None else rows

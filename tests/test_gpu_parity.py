@@ -1,0 +1,296 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against the CPU oracle
+on the same seeded inputs, against the committed golden vectors from the reference, and
+through size-independent properties.  Bit-exact where the arithmetic order is the same
+(oracle TREE16 order == the kernels' order); tolerance stated in the test otherwise.
+"""
+import base64
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cu2rec_amd as cu
+from cu2rec_amd import synth
+from conftest import GOLDEN, ROOT
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+HYPER = (0.01, 0.02, 0.02, 0.02, 0.02)
+
+
+def _toy(name="toy_ratings.csv"):
+    return cu.createSparseMatrix(os.path.join(GOLDEN, name))
+
+
+def _as_orc(m):
+    return orc.CSR(m.indptr, m.indices, m.data, m.rows, m.cols, m.global_bias)
+
+
+def _random_model(rows, cols, f, seed=0, scale=0.1):
+    rng = np.random.RandomState(seed)
+    return ((rng.randn(rows, f) * scale).astype(np.float32), (rng.randn(cols, f) * scale).astype(np.float32),
+            (rng.randn(rows) * scale).astype(np.float32), (rng.randn(cols) * scale).astype(np.float32))
+
+
+def _small_set(users=300, items=120, nnz=6000, seed=1):
+    tr, te = synth.make_ratings(users, items, nnz, min_degree=3, seed=seed)
+    return tr, te
+
+
+# ------------------------------------------------------------------ loss
+
+def test_loss_golden_74():
+    m = _toy()  # tests/test_loss.cu:23-101: P=Q=1 (f=2), biases 1, global_bias forced to 1 -> sum e^2 == 74
+    d = cu.DeviceCSR(m)
+    model = cu.Model(m.rows, m.cols, 2, 1.0, P=np.ones((m.rows, 2)), Q=np.ones((m.cols, 2)), user_bias=np.ones(m.rows),
+                     item_bias=np.ones(m.cols))
+    out = model.loss(d)
+    assert out["sum_sq"] == 74.0
+    assert out["rmse"] == np.float32(np.sqrt(74.0 / 18))
+
+
+@pytest.mark.parametrize("n", [1, 33, 1 << 10, 1 << 16, (1 << 20) + 7])
+def test_total_loss_all_ones(n):
+    from cu2rec_amd.engine import Engine
+    eng = Engine(1, 1, 4, 0.0)  # tests/test_loss.cu:106-147: all-ones residuals -> mae == rmse == 1 exactly
+    mae, rmse = eng.error_metrics(np.ones(n, np.float32))
+    assert mae == 1.0 and rmse == 1.0
+
+
+@pytest.mark.parametrize("f", [1, 2, 10, 50, 64, 100, 128, 300])
+def test_loss_bit_exact_vs_oracle(f):
+    from cu2rec_amd.engine import DeviceRatings, Engine
+    tr, _ = _small_set()
+    P, Q, ub, ib = _random_model(tr.rows, tr.cols, f, seed=f)
+    eng = Engine(tr.rows, tr.cols, f, tr.global_bias, P, Q, ub, ib)
+    got = eng.loss(DeviceRatings(tr, eng.device), want_errors=True)
+    want = orc.loss(_as_orc(tr), P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_TREE16, acc=orc.ACC_F64,
+                    want_errors=True)
+    np.testing.assert_array_equal(got["errors"], want["errors"])  # residuals: same order of operations -> same bits
+    # the double sums are added in a different order (per group, per block, then blocks): 1e-12 relative
+    assert abs(got["sum_sq"] - want["sum_sq"]) <= 1e-12 * want["sum_sq"]
+    assert abs(got["sum_abs"] - want["sum_abs"]) <= 1e-12 * want["sum_abs"]
+    assert got["rmse"] == want["rmse"] and got["mae"] == want["mae"]
+    # against the reference's own summation order (sequential dot): float rounding of the dot only
+    ref = orc.loss(_as_orc(tr), P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_SEQ, acc=orc.ACC_F64)
+    assert abs(got["rmse"] - ref["rmse"]) <= 2e-6 * max(1.0, ref["rmse"])
+
+
+def test_loss_empty_users_and_ragged_rows():
+    m = _toy("toy_missing_user.csv")  # user 2 has no ratings
+    P, Q, ub, ib = _random_model(m.rows, m.cols, 10, seed=3, scale=1.0)
+    model = cu.Model(m.rows, m.cols, 10, m.global_bias, P, Q, ub, ib)
+    got = model.loss(cu.DeviceCSR(m))
+    want = orc.loss(_as_orc(m), P, Q, ub, ib, m.global_bias, dot_order=orc.DOT_TREE16)
+    assert got["rmse"] == want["rmse"] and got["mae"] == want["mae"]
+    # a test set with fewer users than the model (Appendix quirk 6)
+    t = _toy("toy_user_spaces.csv")
+    got = model.loss(cu.DeviceCSR(cu.HostCSR(t.indptr, t.indices, t.data, t.rows, m.cols, t.global_bias)))
+    want = orc.loss(_as_orc(t), P, Q, ub, ib, m.global_bias, dot_order=orc.DOT_TREE16)
+    assert got["rmse"] == want["rmse"]
+
+
+# ------------------------------------------------------------------ SGD, serial order: exact
+
+@pytest.mark.parametrize("f,iters", [(1, 7), (2, 10), (10, 25), (50, 10), (100, 10), (128, 5), (300, 3)])
+def test_sgd_serial_bit_exact_vs_oracle(f, iters):
+    tr, _ = _small_set()
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)  # library-side seed-42 init
+    np.testing.assert_array_equal(model.download()[0], P)
+    model.sgd(cu.DeviceCSR(tr), HYPER, seed=42, iter0=0, n_iters=iters, mode="serial")
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, iters, dot_order=orc.DOT_TREE16)
+    gP, gQ, gub, gib = model.download()
+    np.testing.assert_array_equal(gP, P)
+    np.testing.assert_array_equal(gQ, Q)
+    np.testing.assert_array_equal(gub, ub)
+    np.testing.assert_array_equal(gib, ib)
+
+
+def test_sgd_serial_resume_and_frozen_items():
+    tr, _ = _small_set(seed=4)
+    f = 10
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    d = cu.DeviceCSR(tr)
+    model.sgd(d, HYPER, 7, 0, 3, mode="serial")
+    model.sgd(d, HYPER, 7, 3, 4, mode="serial")  # resumed stream == one run of 7
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 7, 0, 7, dot_order=orc.DOT_TREE16)
+    for g, w in zip(model.download(), (P, Q, ub, ib)):
+        np.testing.assert_array_equal(g, w)
+    # is_train == false: Q and item_bias stay put (config.h:41, sgd.cu:61,70)
+    model.sgd(d, HYPER, 7, 7, 2, mode="serial", update_items=False)
+    Q0, ib0 = Q.copy(), ib.copy()
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 7, 7, 2, dot_order=orc.DOT_TREE16,
+                       update_items=False)
+    gP, gQ, gub, gib = model.download()
+    np.testing.assert_array_equal(gQ, Q0)
+    np.testing.assert_array_equal(gib, ib0)
+    np.testing.assert_array_equal(gP, P)
+
+
+def test_sgd_serial_vs_reference_golden():
+    """GPU (serial order) against the dumps of the reference CPU twin itself.  The only difference
+    is the summation order of the f-term dot product (tree vs sequential): <= 1e-5 absolute on every
+    parameter for these runs (north star: 1e-4 RMSE)."""
+    cases = json.load(open(os.path.join(GOLDEN, "ref_sgd_golden.json")))["cases"]
+    n = 0
+    for case in cases:
+        if "f32_le_b64" not in case["P"]:
+            continue  # the reference's bundled dataset does not travel
+        tr = _toy(case["train"])
+        cur, total, f, lr, seed, pr, qr, ur, ir = case["cfg"]
+        model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+        model.sgd(cu.DeviceCSR(tr), (lr, pr, qr, ur, ir), seed, cur, total, mode="serial")
+        got = model.download()
+        for name, g in zip(("P", "Q", "user_bias", "item_bias"), got):
+            want = np.frombuffer(base64.b64decode(case[name]["f32_le_b64"]), np.float32).reshape(g.shape)
+            assert np.abs(g - want).max() <= 1e-5, (case["cfg"], name)
+        te = _toy(case["test"])
+        rmse = model.loss(cu.DeviceCSR(cu.HostCSR(te.indptr, te.indices, te.data, te.rows, tr.cols)))["rmse"]
+        assert abs(rmse - float(case["lines"][-1]["rmse"])) <= 1e-5
+        n += 1
+    assert n >= 10
+
+
+# ------------------------------------------------------------------ SGD, Hogwild
+
+def test_sgd_hogwild_exact_when_no_item_is_shared():
+    # every user rates only its own item: no two updates of an iteration touch the same row, so
+    # the parallel schedule has the sequential one's result bit for bit
+    n, f = 5000, 100
+    rng = np.random.RandomState(0)
+    m = cu.HostCSR(np.arange(n + 1), rng.permutation(n), rng.randint(1, 6, n).astype(np.float32), n, n, 3.0)
+    P, Q, ub, ib = orc.init_model(n, n, f)
+    model = cu.Model(n, n, f, 3.0)
+    model.sgd(cu.DeviceCSR(m), HYPER, 42, 0, 20, mode="hogwild")
+    orc.sgd_iterations(_as_orc(m), P, Q, ub, ib, 3.0, HYPER, 42, 0, 20, dot_order=orc.DOT_TREE16)
+    for g, w in zip(model.download(), (P, Q, ub, ib)):
+        np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.parametrize("f", [10, 100])
+def test_sgd_hogwild_one_iteration_is_jacobi(f):
+    """One Hogwild iteration: every user's P row / bias is the update computed from the item row as it
+    was at the start of the launch or as some concurrent update left it; for items sampled by exactly
+    one user this is the start-of-iteration row, so those users and items must match the oracle's
+    single update bit for bit.  Shared items must hold values produced by one of their updates."""
+    tr, _ = _small_set(users=2000, items=300, nnz=40000, seed=9)
+    P0, Q0, ub0, ib0 = _random_model(tr.rows, tr.cols, f, seed=2)
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias, P0, Q0, ub0, ib0)
+    model.sgd(cu.DeviceCSR(tr), HYPER, 42, 5, 1, mode="hogwild")
+    gP, gQ, gub, gib = model.download()
+    items = np.array([tr.indices[orc.sample(42, u, 5, tr.indptr[u], tr.indptr[u + 1])] for u in range(tr.rows)])
+    counts = np.bincount(items, minlength=tr.cols)
+    o = _as_orc(tr)
+    n_unique = 0
+    for u in range(tr.rows):
+        if counts[items[u]] != 1:
+            continue
+        P, Q, ub, ib = P0.copy(), Q0.copy(), ub0.copy(), ib0.copy()
+        orc.sgd_one(o, u, P, Q, ub, ib, tr.global_bias, HYPER, 42, 5, dot_order=orc.DOT_TREE16)
+        np.testing.assert_array_equal(gP[u], P[u])
+        np.testing.assert_array_equal(gQ[items[u]], Q[items[u]])
+        assert gub[u] == ub[u] and gib[items[u]] == ib[items[u]]
+        n_unique += 1
+    assert n_unique > 20
+    untouched = counts == 0
+    np.testing.assert_array_equal(gQ[untouched], Q0[untouched])
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()  # tests/test_sgd.cu:134-145
+
+
+def test_sgd_hogwild_converges_like_the_oracle():
+    """Hogwild vs the sequential oracle on the same sample stream: test RMSE after 300 iterations within
+    2e-2 (lost updates on popular items slow Hogwild down a little), both well below the
+    starting RMSE."""
+    tr, te = _small_set(users=3000, items=400, nnz=90000, seed=11)
+    f, iters = 16, 300
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    start = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias)["rmse"]
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, iters, dot_order=orc.DOT_TREE16)
+    want = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias)["rmse"]
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    model.sgd(cu.DeviceCSR(tr), HYPER, 42, 0, iters, mode="hogwild")
+    got = model.loss(cu.DeviceCSR(te))["rmse"]
+    assert want < start - 0.05 and got < start - 0.05
+    assert abs(got - want) < 2e-2
+
+
+# ------------------------------------------------------------------ train() and the CLI
+
+def test_train_schedule_matches_oracle():
+    tr, te = _small_set(seed=5)
+    cfg = cu.default_config(total_iterations=40, n_factors=10, check_error=8, learning_rate=0.05, patience=1.0)
+    ocfg = orc.default_config(total_iterations=40, n_factors=10, check_error=8, learning_rate=0.05, patience=1.0)
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, 10)
+    log = orc.train(_as_orc(tr), _as_orc(te), ocfg, P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_TREE16,
+                    acc=orc.ACC_F64, schedule=orc.SCHED_PATIENCE)
+    gP, gQ, losses, gub, gib, stats = cu.train(tr, te, cfg, mode="serial", verbose=False, return_stats=True)
+    np.testing.assert_array_equal(gP, P)
+    np.testing.assert_array_equal(gQ, Q)
+    checked = [e["iteration"] - 1 for e in log]
+    assert checked == [0, 7, 15, 23, 31, 39]  # training.cu:118
+    for e in log:
+        assert losses[e["iteration"] - 1] == e["test_rmse"]
+    assert np.isnan(losses[[i for i in range(40) if i not in checked]]).all()
+    assert cfg.learning_rate == ocfg.learning_rate and cfg.cur_iterations == 40 == ocfg.cur_iterations
+    assert stats.n_checks == 6 and stats.last_test_rmse == log[-1]["test_rmse"]
+
+
+def test_training_loop_loss_goes_down():
+    m = _toy()  # tests/test_training.cu:20-55: 10 iterations, f=2, lr 1e-3, reg .1, train == test
+    cfg = cu.default_config(total_iterations=10, n_factors=2, learning_rate=1e-3, P_reg=0.1, Q_reg=0.1,
+                            user_bias_reg=0.1, item_bias_reg=0.1, seed=42)
+    _, _, losses, _, _ = cu.train(m, m, cfg, verbose=False)
+    assert losses[0] >= losses[9]
+
+
+def test_bin_mf_cli(tmp_path):
+    exe = os.path.join(ROOT, "bin", "mf")
+    assert os.path.exists(exe), "bin/mf not built"
+    train = tmp_path / "ratings.csv"
+    train.write_text(open(os.path.join(GOLDEN, "toy_ratings.csv")).read())
+    cfgp = tmp_path / "c.cfg"
+    cfgp.write_text("0 20 4 0.01 42 0.02 0.02 0.02 0.02\n")
+    out = subprocess.run([exe, "-c", str(cfgp), "-m", "serial", str(train), os.path.join(GOLDEN, "toy_ratings2.csv")],
+                         stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "Free memory:" in out and "Hyperparameters:" in out and "n_factors: 4" in out
+    assert "TRAIN: Iteration 1 GPU MAE:" in out and "TEST: Iteration 20 GPU MAE:" in out
+    assert "Time taken for 20 of iterations is" in out
+    # five component files next to the training file (mf.cu:83-87)
+    tr = _toy()
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, 4)
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, 20, dot_order=orc.DOT_TREE16)
+    for comp, want in (("p", P), ("q", Q), ("user_bias", ub), ("item_bias", ib)):
+        path = tmp_path / ("ratings_f4_%s.csv" % comp)
+        orc.write_csv(str(tmp_path / "want.csv"), want)
+        assert path.read_text() == (tmp_path / "want.csv").read_text(), comp
+    assert (tmp_path / "ratings_f4_global_bias.csv").read_text() == "%f\n" % tr.global_bias
+    assert subprocess.run([exe]).returncode == 255  # mf.cu:17-19: return -1
+    assert subprocess.run([exe, "-z"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode == 1
+
+
+# ------------------------------------------------------------------ larger shapes: properties
+
+def test_ml1m_shape_properties():
+    """ML-1M shape, f=50 (BASELINE.json configs[1]): loss agrees with the oracle to 1e-6, RMSE falls
+    monotonically over the first checks, parameters stay finite, untouched items keep their rows."""
+    tr, te = synth.make_named("ml-1m")
+    f = 50
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    dtr, dte = cu.DeviceCSR(tr), cu.DeviceCSR(te)
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    want = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_TREE16)
+    got = model.loss(dte)
+    assert got["rmse"] == want["rmse"] and abs(got["sum_sq"] - want["sum_sq"]) <= 1e-12 * want["sum_sq"]
+    last = got["rmse"]
+    for k in range(4):
+        model.sgd(dtr, HYPER, 42, 100 * k, 100, mode="hogwild")
+        cur = model.loss(dte)["rmse"]
+        assert cur < last
+        last = cur
+    for a in model.download():
+        assert np.isfinite(a).all()

@@ -1,0 +1,141 @@
+"""CPU-only checks of the product's host side through the C ABI (no GPU compute calls):
+the library loads, exports every symbol include/cu2rec_amd.h declares, and its reader / CSR
+builder / init / sampler / writer agree with the oracle and the reference's known answers."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cu2rec_amd as cu
+from cu2rec_amd import _lib
+from conftest import GOLDEN, ROOT
+from oracle import oracle as orc
+
+
+def test_header_symbols_are_exported():
+    header = open(os.path.join(ROOT, "include", "cu2rec_amd.h")).read()
+    declared = set(re.findall(r"\b(cu2rec_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cu2rec_status"}
+    assert len(declared) >= 35
+    L = cu.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "missing symbol " + name
+        assert name in _lib.SIGNATURES, "no ctypes signature for " + name
+    assert L.cu2rec_version() == 100
+
+
+def test_compute_fails_loudly_without_gpu():
+    if cu.device_count() > 0:
+        pytest.skip("a GPU is present")
+    m = cu.createSparseMatrix(os.path.join(GOLDEN, "toy_ratings.csv"))
+    with pytest.raises(cu.Cu2recError) as e:
+        cu.DeviceCSR(m)
+    assert e.value.status == -4  # CU2REC_ENODEVICE: no CPU fallback
+    with pytest.raises(cu.Cu2recError):
+        cu.Model(m.rows, m.cols, 4, m.global_bias)
+
+
+def test_csr_goldens():
+    m = cu.createSparseMatrix(os.path.join(GOLDEN, "toy_ratings.csv"))  # tests/test_util.cu:20-34,98-142
+    assert (m.rows, m.cols, m.nnz) == (6, 5, 18) and abs(m.global_bias - 3.5556) < 1e-3
+    assert m.indptr.tolist() == [0, 4, 7, 10, 13, 16, 18]
+    assert m.indices.tolist() == [0, 1, 2, 4, 0, 1, 2, 0, 1, 2, 0, 1, 2, 1, 3, 4, 3, 4]
+    assert m.data.tolist() == [1, 1, 1, 5, 3, 3, 3, 4, 4, 4, 5, 5, 5, 2, 4, 4, 5, 5]
+    m = cu.createSparseMatrix(os.path.join(GOLDEN, "toy_missing_user.csv"))  # tests/test_util.cu:146-189
+    assert m.indptr.tolist() == [0, 4, 4, 7, 10, 13, 15]
+    m = cu.createSparseMatrix(os.path.join(GOLDEN, "toy_user_spaces.csv"))
+    assert m.indices.tolist() == [0, 1, 3] and m.data.tolist() == [1, 1, 5]
+
+
+def test_read_array_golden():
+    a = cu.read_array(os.path.join(GOLDEN, "toy_Q.csv"))  # tests/test_util.cu:36-46
+    assert a.shape == (2, 5) and a.ravel().tolist() == list(range(10))
+
+
+def test_reader_matches_oracle_on_random_files(tmp_path):
+    rng = np.random.RandomState(3)
+    for trial in range(5):
+        n_users, n_items = int(rng.randint(1, 60)), int(rng.randint(1, 40))
+        rows = []
+        for u in range(1, n_users + 1):
+            if rng.rand() < 0.15:
+                continue
+            for i in rng.permutation(n_items)[: rng.randint(1, n_items + 1)] + 1:
+                rows.append((u, int(i), float(rng.choice([0.5, 1, 1.5, 2, 2.5, 3, 3.5, 4, 4.5, 5]))))
+        p = tmp_path / ("r%d.csv" % trial)
+        sep = ", " if trial % 2 else ","
+        p.write_text("userId,itemId,rating\n" + "\n".join("%d%s%d%s%s" % (u, sep, i, sep, repr(r)) for u, i, r in rows)
+                     + ("\n" if trial % 3 == 0 else ""))
+        if not rows:
+            continue
+        a, b = cu.createSparseMatrix(str(p)), orc.read_csv(str(p))
+        assert (a.rows, a.cols, a.nnz) == (b.rows, b.cols, b.nnz)
+        assert np.float32(a.global_bias) == np.float32(b.global_bias)
+        np.testing.assert_array_equal(a.indptr, b.indptr)
+        np.testing.assert_array_equal(a.indices, b.indices)
+        np.testing.assert_array_equal(a.data, b.data)
+
+
+def test_unsorted_and_missing_files_are_errors(tmp_path):
+    p = tmp_path / "bad.csv"
+    p.write_text("userId,itemId,rating\n2,1,3.0\n1,1,4.0\n")
+    with pytest.raises(cu.Cu2recError):
+        cu.createSparseMatrix(str(p))
+    with pytest.raises(cu.Cu2recError) as e:
+        cu.readCSV(str(tmp_path / "nope.csv"))
+    assert e.value.status == -2
+
+
+def test_init_matches_reference_known_answers():
+    np.testing.assert_array_equal(cu.initialize_normal_array(6, 10),
+                                  np.array([0.122192137, -0.051696416, 0.086963594, 0.0721332654, 0.158855632,
+                                            0.161821708], np.float32))
+    for f in (1, 2, 50, 100, 300):
+        np.testing.assert_array_equal(cu.initialize_normal_array(1000, f), orc.normal_fill(1000, f))
+    np.testing.assert_array_equal(cu.initialize_normal_array(64, 7, 0.5, 2.0, 9), orc.normal_fill(64, 7, 0.5, 2.0, 9))
+
+
+def test_sampler_matches_oracle():
+    rng = np.random.RandomState(5)
+    L = cu.lib()
+    for _ in range(5000):
+        seed, user, it = int(rng.randint(0, 2**31)), int(rng.randint(0, 2**31)), int(rng.randint(0, 2**31))
+        low, n = int(rng.randint(0, 10**6)), int(rng.randint(1, 20000))
+        assert L.cu2rec_sampler_draw(seed, user, it) == orc.lib().orc_draw(seed, user, it)
+        assert L.cu2rec_sampler_index(seed, user, it, low, low + n) == orc.sample(seed, user, it, low, low + n)
+
+
+def test_config_roundtrip_and_defaults(tmp_path):
+    c = cu.default_config()
+    assert (c.total_iterations, c.n_factors, c.seed, c.n_threads, c.check_error) == (5000, 50, 42, 32, 500)
+    assert abs(c.learning_rate - 0.01) < 1e-9 and abs(c.P_reg - 0.02) < 1e-9 and c.patience == 2.0
+    p = tmp_path / "t.cfg"
+    p.write_text("0 100 10 0.0001 42 0.2 0.1 0.1 0.1")  # data/test/test_config.cfg
+    c = cu.read_config(str(p))
+    assert c.total_iterations == 100 and abs(c.P_reg - 0.2) < 1e-7  # tests/test_config.cu:20-24
+    q = tmp_path / "u.cfg"
+    cu.write_config(str(q), c)
+    d, o = cu.read_config(str(q)), orc.read_config(str(q))
+    for name, _ in cu.Config._fields_[:9]:
+        assert getattr(c, name) == getattr(d, name) == getattr(o, name)
+    with pytest.raises(cu.Cu2recError):
+        cu.read_config(str(tmp_path / "missing.cfg"))
+
+
+def test_writer_matches_oracle(tmp_path):
+    a = (np.random.RandomState(0).randn(7, 5) * 3).astype(np.float32)
+    cu.writeToFile(str(tmp_path), "base", "p", a, 7, 5, 5)
+    orc.write_csv(str(tmp_path / "o.csv"), a)
+    assert (tmp_path / "base_f5_p.csv").read_text() == (tmp_path / "o.csv").read_text()  # util.cu:86-103
+    assert (tmp_path / "base_f5_p.csv").read_text().split("\n")[0].count(",") == 4
+
+
+def test_shard_plan_and_slice():
+    plan = cu.shard_plan(10, 3)
+    assert plan.tolist() == [0, 3, 6, 10]
+    m = cu.createSparseMatrix(os.path.join(GOLDEN, "toy_ratings.csv"))
+    s = m.slice_users(2, 5)
+    assert s.indptr.tolist() == [0, 3, 6, 9] and s.nnz == 9 and s.indices.tolist() == m.indices[7:16].tolist()
+    whole = [m.slice_users(a, b) for a, b in zip(cu.shard_plan(m.rows, 4)[:-1], cu.shard_plan(m.rows, 4)[1:])]
+    assert sum(w.nnz for w in whole) == m.nnz
