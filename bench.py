@@ -102,7 +102,19 @@ def cpu_baseline(train, test, f, hyper, budget_s=12.0):
     return out
 
 
+def log(msg):
+    sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.perf_counter()
+
+
 def main():
+    import faulthandler
+    faulthandler.enable()
+    if os.environ.get("CU2REC_BENCH_WATCHDOG"):
+        faulthandler.dump_traceback_later(int(os.environ["CU2REC_BENCH_WATCHDOG"]), repeat=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -143,7 +155,9 @@ def main():
     from cu2rec_amd.engine import DeviceRatings, Engine
     from cu2rec_amd.parallel import ShardedSGD
 
+    log("torch + library loaded, device %s" % torch.cuda.get_device_name(device))
     train, test = load_dataset(args.workload, args.seed, rank, barrier)
+    log("dataset ready: %d users, %d items, %d train ratings" % (train.rows, train.cols, train.nnz))
     f = args.factors
     hyper = (0.01, 0.02, 0.02, 0.02, 0.02)  # preprocessing/create_config.py:25-32
     users_active = int(np.count_nonzero(np.diff(train.indptr)))
@@ -154,11 +168,15 @@ def main():
     # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the global population
     job = ShardedSGD(eng, d_train, user_offset=rank * train.rows, sync_every=sync_every, merge=args.merge)
     mode = cu.SGD_HOGWILD if args.mode == "hogwild" else cu.SGD_SERIAL
+    log("model + ratings resident in HBM")
     rmse0 = job.loss(d_test)["rmse"]
+    log("initial test rmse %.6f" % rmse0)
 
     it = 0
     job.run(hyper, 42, it, args.warmup, mode)
     it += args.warmup
+    torch.cuda.synchronize()
+    log("warmup done")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -167,6 +185,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     it += args.steps
+    log("timed region: %d steps in %.4f s" % (args.steps, elapsed))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,6 +203,7 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     kernel_ms_min = float(np.min([a.elapsed_time(b) for a, b in evs]))
 
+    log("kernel avg %.2f us (min %.2f us)" % (1e3 * kernel_ms, 1e3 * kernel_ms_min))
     final = job.loss(d_test)
     bytes_per_update = 16 * f + 32
     alg_bytes = users_active * bytes_per_update

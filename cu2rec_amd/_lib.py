@@ -103,6 +103,14 @@ def lib():
             raise ImportError(
                 "cu2rec_amd: %s is missing. Build it with `make -C cu2rec_amd/csrc` (or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback." % LIB_PATH)
+        # PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  If torch is going
+        # to be used in this process it must be loaded FIRST, so that this library's DT_NEEDED
+        # libamdhip64.so.7 resolves to the runtime torch already holds; loading /opt/rocm's copy first
+        # and torch's afterwards puts two HIP/HSA runtimes in one process (torch then sees no GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header / library mismatch

@@ -45,6 +45,7 @@ class ShardedSGD:
 
     def exchange(self):
         """All-reduce the item-factor deltas and rebase every replica on the merged result."""
+        self.since_sync = 0
         if self.world_size == 1:
             return
         buf = self.engine.pack_item_delta()

@@ -1,0 +1,139 @@
+"""The N>1 host logic on CPU: user sharding + the item-factor exchange over torch.distributed (gloo,
+world_size 2), with an oracle-backed stand-in engine (tests may use the oracle; the product engine is
+HIP-only).  Checks: cadence bookkeeping, same sampler stream as the unsharded run, the merge algebra
+Q = Q_base + scale * sum_k (Q_k - Q_base), global loss reduction."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cu2rec_amd as cu
+from cu2rec_amd import synth
+from cu2rec_amd.parallel import ShardedSGD, plan_users
+from conftest import ROOT
+from oracle import oracle as orc
+
+HYPER = (0.01, 0.02, 0.02, 0.02, 0.02)
+
+
+class OracleEngine:
+    """Same duck-typed surface as cu2rec_amd.engine.Engine, computed by the CPU oracle (test only)."""
+
+    def __init__(self, rows, cols, f, global_bias, P, Q, ub, ib):
+        self.P, self.Q, self.ub, self.ib = P.copy(), Q.copy(), ub.copy(), ib.copy()
+        self.f, self.global_bias = f, global_bias
+        self.device = None
+
+    def sgd(self, ratings, hyper, seed, iter0, n_iters, mode, update_items=True, user_offset=0):
+        # the oracle keys its sampler by row index; emulate a global user id by shifting rows
+        o = orc.CSR(ratings.indptr, ratings.indices, ratings.data, ratings.rows, ratings.cols)
+        for i in range(n_iters):
+            for x in range(ratings.rows):
+                lo, hi = int(o.indptr[x]), int(o.indptr[x + 1])
+                if lo == hi:
+                    continue
+                # one update with the draw of (user_offset + x): temporarily present a 1-row view
+                y_i = orc.sample(seed, user_offset + x, iter0 + i, lo, hi)
+                self._update(x, int(o.indices[y_i]), float(o.data[y_i]), hyper, update_items)
+
+    def _update(self, x, y, r, h, update_items):
+        lr, pr, qr, ur, ir = (np.float32(v) for v in h)
+        p, q = self.P[x].copy(), self.Q[y].copy()
+        pred = orc.lib().orc_predict(self.f, p.ctypes.data_as(orc.C.POINTER(orc.C.c_float)),
+                                     q.ctypes.data_as(orc.C.POINTER(orc.C.c_float)), float(self.ub[x]),
+                                     float(self.ib[y]), float(self.global_bias), orc.DOT_SEQ)
+        err = np.float32(r) - np.float32(pred)
+        self.P[x] = p + lr * (err * q - pr * p)
+        if update_items:
+            self.Q[y] = q + lr * (err * p - qr * q)
+            self.ib[y] = self.ib[y] + lr * (err - ir * self.ib[y])
+        self.ub[x] = self.ub[x] + lr * (err - ur * self.ub[x])
+
+    def snapshot_items(self):
+        self.Q_base, self.ib_base = self.Q.copy(), self.ib.copy()
+
+    def pack_item_delta(self):
+        self._buf = torch.from_numpy(np.concatenate([(self.Q - self.Q_base).ravel(), self.ib - self.ib_base]))
+        return self._buf
+
+    def apply_item_delta(self, scale):
+        d = self._buf.numpy() * np.float32(scale)
+        n = self.Q.size
+        self.Q = self.Q_base + d[:n].reshape(self.Q.shape)
+        self.ib = self.ib_base + d[n:]
+        self.snapshot_items()
+
+    def loss(self, ratings):
+        o = orc.CSR(ratings.indptr, ratings.indices, ratings.data, ratings.rows, ratings.cols)
+        return orc.loss(o, self.P, self.Q, self.ub, self.ib, self.global_bias)
+
+
+def test_single_rank_cadence_terminates_and_matches_oracle():
+    tr, te = synth.make_ratings(60, 30, 600, min_degree=2, seed=2)
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, 8)
+    eng = OracleEngine(tr.rows, tr.cols, 8, tr.global_bias, P, Q, ub, ib)
+    job = ShardedSGD(eng, tr, sync_every=3)
+    assert job.run(HYPER, 42, 0, 10, cu.SGD_HOGWILD) == 10  # crosses several sync points with world_size 1
+    orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols), P, Q, ub, ib, tr.global_bias, HYPER,
+                       42, 0, 10)
+    np.testing.assert_allclose(eng.P, P, atol=1e-6)
+    np.testing.assert_allclose(eng.Q, Q, atol=1e-6)
+    assert job.exchanges == 0
+    assert job.loss(te)["n"] == te.nnz
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr, te = synth.make_ratings(80, 25, 900, min_degree=2, seed=5)
+    f = 6
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    bounds = plan_users(tr.rows, world)
+    u0, u1 = bounds[rank], bounds[rank + 1]
+    shard, shard_te = tr.slice_users(u0, u1), te.slice_users(u0, u1)
+    eng = OracleEngine(u1 - u0, tr.cols, f, tr.global_bias, P[u0:u1], Q, ub[u0:u1], ib)
+    job = ShardedSGD(eng, shard, user_offset=u0, sync_every=4, merge="mean")
+    job.run(HYPER, 42, 0, 10, cu.SGD_HOGWILD)  # exchanges after iterations 4 and 8
+    res = job.loss(shard_te)
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), P=eng.P, Q=eng.Q, ub=eng.ub, ib=eng.ib, u0=u0, u1=u1,
+             exchanges=job.exchanges, rmse=res["rmse"], n=res["n"])
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo(tmp_path):
+    world, port = 2, 29000 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(str(tmp_path / ("r%d.npz" % k))) for k in range(world)]
+    assert int(r[0]["exchanges"]) == 2 and int(r[1]["exchanges"]) == 2
+    # single-process emulation of the same schedule: two logical shards, merge by mean of deltas
+    tr, te = synth.make_ratings(80, 25, 900, min_degree=2, seed=5)
+    f = 6
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    bounds = plan_users(tr.rows, world)
+    engs = [OracleEngine(bounds[k + 1] - bounds[k], tr.cols, f, tr.global_bias, P[bounds[k]:bounds[k + 1]], Q,
+                         ub[bounds[k]:bounds[k + 1]], ib) for k in range(world)]
+    shards = [tr.slice_users(bounds[k], bounds[k + 1]) for k in range(world)]
+    Qb, ibb = Q.copy(), ib.copy()
+    it = 0
+    for n in (4, 4, 2):
+        for k in range(world):
+            engs[k].sgd(shards[k], HYPER, 42, it, n, cu.SGD_HOGWILD, True, bounds[k])
+        it += n
+        if n == 4:
+            dQ = sum(e.Q - Qb for e in engs) / np.float32(world)
+            dib = sum(e.ib - ibb for e in engs) / np.float32(world)
+            Qb, ibb = Qb + dQ, ibb + dib
+            for e in engs:
+                e.Q, e.ib = Qb.copy(), ibb.copy()
+    for k in range(world):
+        np.testing.assert_allclose(r[k]["P"], engs[k].P, atol=1e-6)
+        np.testing.assert_allclose(r[k]["Q"], engs[k].Q, atol=1e-6)
+        np.testing.assert_allclose(r[k]["ib"], engs[k].ib, atol=1e-6)
+    # after the last exchange both replicas agreed; they then drifted for 2 local iterations
+    assert float(r[0]["rmse"]) == float(r[1]["rmse"]) and int(r[0]["n"]) == te.nnz  # global loss is all-reduced
