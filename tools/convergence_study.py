@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Test-RMSE trajectory of the GPU SGD modes next to the sequential CPU oracle, same data, same sampler
+stream (tools/, not shipped in the product path; uses the oracle as the checker).
+
+usage: tools/convergence_study.py [--workload ml-1m] [--factors 50] [--iters 2000] [--every 250] [--modes hogwild,...]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="ml-1m")
+    ap.add_argument("--factors", type=int, default=50)
+    ap.add_argument("--iters", type=int, default=2000)
+    ap.add_argument("--every", type=int, default=250)
+    ap.add_argument("--modes", default="hogwild")
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--no-oracle", action="store_true")
+    args = ap.parse_args()
+    import bench
+    import cu2rec_amd as cu
+    from oracle import oracle as orc
+    train, test = bench.load_dataset(args.workload, 20240917, 0, lambda: None)
+    f, hyper = args.factors, (args.lr, 0.02, 0.02, 0.02, 0.02)
+    d_tr, d_te = cu.DeviceCSR(train), cu.DeviceCSR(test)
+    out = {"workload": args.workload, "f": f, "hyper": hyper, "iters": args.iters, "curves": {}}
+    for mode in args.modes.split(","):
+        model = cu.Model(train.rows, train.cols, f, train.global_bias)
+        curve, t_sgd = [(0, model.loss(d_te)["rmse"], model.loss(d_tr)["rmse"])], 0.0
+        for it in range(0, args.iters, args.every):
+            t0 = time.perf_counter()
+            model.sgd(d_tr, hyper, 42, it, args.every, mode=mode)
+            r = model.loss(d_te)
+            t_sgd += time.perf_counter() - t0
+            curve.append((it + args.every, r["rmse"], model.loss(d_tr)["rmse"]))
+        out["curves"][mode] = {"points": curve, "seconds": t_sgd}
+        print(mode, "%.2fs" % t_sgd, " ".join("%d:%.5f" % (a, b) for a, b, _ in curve), flush=True)
+    if not args.no_oracle:
+        o_tr = orc.CSR(train.indptr, train.indices, train.data, train.rows, train.cols, train.global_bias)
+        o_te = orc.CSR(test.indptr, test.indices, test.data, test.rows, test.cols, test.global_bias)
+        P, Q, ub, ib = orc.init_model(train.rows, train.cols, f)
+        curve = [(0, orc.loss(o_te, P, Q, ub, ib, train.global_bias)["rmse"], orc.loss(o_tr, P, Q, ub, ib, train.global_bias)["rmse"])]
+        t0 = time.perf_counter()
+        for it in range(0, args.iters, args.every):
+            orc.sgd_iterations(o_tr, P, Q, ub, ib, train.global_bias, hyper, 42, it, args.every, dot_order=orc.DOT_TREE16)
+            curve.append((it + args.every, orc.loss(o_te, P, Q, ub, ib, train.global_bias)["rmse"],
+                          orc.loss(o_tr, P, Q, ub, ib, train.global_bias)["rmse"]))
+        out["curves"]["oracle_sequential"] = {"points": curve, "seconds": time.perf_counter() - t0}
+        print("oracle", "%.2fs" % (time.perf_counter() - t0), " ".join("%d:%.5f" % (a, b) for a, b, _ in curve), flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
