@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="ml-20m", choices=["ml-100k", "ml-1m", "ml-20m", "netflix"])
     ap.add_argument("--factors", type=int, default=100)
-    ap.add_argument("--mode", default="hogwild", choices=["hogwild", "serial"])
+    ap.add_argument("--mode", default="hogwild", choices=["hogwild", "serial", "ordered"])
     ap.add_argument("--sync-every", type=int, default=0, help="steps between item-factor all-reduces (0 = one epoch)")
     ap.add_argument("--merge", default="mean", choices=["mean", "sum"])
     ap.add_argument("--seed", type=int, default=20240917)
@@ -167,7 +167,7 @@ def main():
     d_train, d_test = DeviceRatings(train, device), DeviceRatings(test, device)
     # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the global population
     job = ShardedSGD(eng, d_train, user_offset=rank * train.rows, sync_every=sync_every, merge=args.merge)
-    mode = cu.SGD_HOGWILD if args.mode == "hogwild" else cu.SGD_SERIAL
+    mode = {"hogwild": cu.SGD_HOGWILD, "serial": cu.SGD_SERIAL, "ordered": cu.SGD_ORDERED}[args.mode]
     log("model + ratings resident in HBM")
     rmse0 = job.loss(d_test)["rmse"]
     log("initial test rmse %.6f" % rmse0)

@@ -71,6 +71,10 @@ SIGNATURES = {
     "cu2rec_sampler_index": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
     "cu2rec_sgd_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,
                                     C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "cu2rec_schedule_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "cu2rec_schedule_destroy": (None, [_P]),
+    "cu2rec_sgd_update_ordered": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,
+                                            C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "cu2rec_loss_workspace_bytes": (C.c_size_t, []),
     "cu2rec_loss": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float, C.c_int, _P,
                               _P, _dp, _dp, _fp, _fp, _P]),

@@ -12,8 +12,8 @@ import numpy as np
 
 from ._lib import Config, Cu2recError, Hyper, TrainStats, check, lib
 
-SGD_HOGWILD, SGD_SERIAL = 0, 1
-MODES = {"hogwild": SGD_HOGWILD, "serial": SGD_SERIAL}
+SGD_HOGWILD, SGD_SERIAL, SGD_ORDERED = 0, 1, 2
+MODES = {"hogwild": SGD_HOGWILD, "serial": SGD_SERIAL, "ordered": SGD_ORDERED}
 
 
 def _mode(mode):
@@ -306,6 +306,35 @@ def sgd_update(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias,
     check(lib().cu2rec_sgd_update(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias,
                                   float(global_bias), n_factors, C.byref(h), int(seed), int(iter0), int(n_iters),
                                   _mode(mode), 1 if update_items else 0, int(user_offset), stream))
+
+
+class Schedule:
+    """Workspace of the ordered mode for one device CSR (cu2rec_schedule)."""
+
+    def __init__(self, indptr, indices, n_rows, n_cols, nnz):
+        self._h = C.c_void_p()
+        check(lib().cu2rec_schedule_create(indptr, indices, n_rows, n_cols, nnz, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().cu2rec_schedule_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sgd_update_ordered(schedule, indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias,
+                       global_bias, n_factors, hyper, seed, iter0, n_iters, update_items=True, user_offset=0,
+                       stream=None):
+    """cu2rec_sgd_update_ordered on raw device addresses."""
+    h = hyper if isinstance(hyper, Hyper) else Hyper(*[float(x) for x in hyper])
+    check(lib().cu2rec_sgd_update_ordered(schedule._h, indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias,
+                                          item_bias, float(global_bias), n_factors, C.byref(h), int(seed), int(iter0),
+                                          int(n_iters), 1 if update_items else 0, int(user_offset), stream))
 
 
 def loss_raw(indptr, indices, data, n_rows, nnz, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,

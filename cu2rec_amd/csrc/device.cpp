@@ -47,20 +47,16 @@ PartialSums collect_partials(const double *device_partials, int blocks, hipStrea
 
 }  // namespace
 
-void sgd_update(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P, int ldp,
-                float *Q, int ldq, float *user_bias, float *item_bias, float global_bias, int n_factors,
-                const cu2rec_hyper &hyper, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
-                int user_offset, hipStream_t stream) {
+SgdArgs make_sgd_args(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P,
+                      int ldp, float *Q, int ldq, float *user_bias, float *item_bias, float global_bias, int n_factors,
+                      const cu2rec_hyper &hyper, uint64_t seed, int update_items, int user_offset) {
     require(indptr && P && Q && user_bias && item_bias, "cu2rec_sgd_update: null device pointer");
-    require(n_rows >= 0 && n_cols >= 0 && n_factors > 0 && n_iters >= 0, "cu2rec_sgd_update: bad shape");
-    require(mode == CU2REC_SGD_HOGWILD || mode == CU2REC_SGD_SERIAL, "cu2rec_sgd_update: unknown mode");
+    require(n_rows >= 0 && n_cols >= 0 && n_factors > 0, "cu2rec_sgd_update: bad shape");
+    require(n_rows == 0 || (indices && data), "cu2rec_sgd_update: null device pointer");
     check_ld(ldp, n_factors, "P");
     check_ld(ldq, n_factors, "Q");
     check_aligned(P, "P");
     check_aligned(Q, "Q");
-    if (n_rows == 0 || n_iters == 0) return;
-    require(indices && data, "cu2rec_sgd_update: null device pointer");
-    require_device();
     SgdArgs a{};
     a.indptr = indptr;
     a.indices = indices;
@@ -78,6 +74,20 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
     a.seed = seed;
     a.update_items = update_items ? 1 : 0;
     a.user_offset = user_offset;
+    return a;
+}
+
+void sgd_update(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P, int ldp,
+                float *Q, int ldq, float *user_bias, float *item_bias, float global_bias, int n_factors,
+                const cu2rec_hyper &hyper, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
+                int user_offset, hipStream_t stream) {
+    require(mode == CU2REC_SGD_HOGWILD || mode == CU2REC_SGD_SERIAL,
+            "cu2rec_sgd_update: unknown mode (CU2REC_SGD_ORDERED needs cu2rec_sgd_update_ordered and a schedule)");
+    require(n_iters >= 0, "cu2rec_sgd_update: bad iteration count");
+    SgdArgs a = make_sgd_args(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias, global_bias,
+                              n_factors, hyper, seed, update_items, user_offset);
+    if (n_rows == 0 || n_iters == 0) return;
+    require_device();
     if (mode == CU2REC_SGD_SERIAL) {
         // one launch walks all iterations in order
         a.iter0 = iter0;
@@ -93,6 +103,26 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
         }
     }
     CU2REC_HIP(hipGetLastError());
+}
+
+void sgd_update_ordered(OrderedSchedule &schedule, const int *indptr, const int *indices, const float *data,
+                        int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
+                        float *item_bias, float global_bias, int n_factors, const cu2rec_hyper &hyper, uint64_t seed,
+                        uint64_t iter0, int n_iters, int update_items, int user_offset, hipStream_t stream) {
+    if (!update_items) {
+        // frozen items: no two updates of an iteration share a written row, so the parallel schedule IS the
+        // sequential result; no chains needed
+        sgd_update(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,
+                   hyper, seed, iter0, n_iters, CU2REC_SGD_HOGWILD, 0, user_offset, stream);
+        return;
+    }
+    require(n_iters >= 0, "cu2rec_sgd_update_ordered: bad iteration count");
+    require(schedule.n_rows == n_rows && schedule.n_cols == n_cols, "cu2rec_sgd_update_ordered: schedule built for another CSR");
+    SgdArgs a = make_sgd_args(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias, global_bias,
+                              n_factors, hyper, seed, update_items, user_offset);
+    if (n_rows == 0 || n_iters == 0) return;
+    require_device();
+    schedule.run(a, iter0, n_iters, stream);
 }
 
 void loss(const int *indptr, const int *indices, const float *data, int n_rows, int nnz, const float *P, int ldp,
@@ -232,6 +262,14 @@ void DeviceModel::download(float *hP, float *hQ, float *hub, float *hib) const {
 void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t seed, uint64_t iter0, int n_iters, int mode,
                       int update_items, hipStream_t stream) {
     require(train.rows <= rows && train.max_item < cols, "cu2rec_model_sgd: ratings exceed the model's shape");
+    if (mode == CU2REC_SGD_ORDERED) {
+        if (!train.schedule)
+            train.schedule.reset(new OrderedSchedule(train.indptr.ptr, train.indices.ptr, train.rows, cols, train.nnz));
+        sgd_update_ordered(*train.schedule, train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr,
+                           ld, Q.ptr, ld, user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters,
+                           update_items, 0, stream);
+        return;
+    }
     sgd_update(train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr, ld, Q.ptr, ld,
                user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters, mode, update_items, 0, stream);
 }
@@ -249,6 +287,11 @@ void DeviceModel::loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq
 
 using namespace cu2rec;
 
+struct cu2rec_schedule {
+    OrderedSchedule impl;
+    template <class... A>
+    explicit cu2rec_schedule(A &&...a) : impl(std::forward<A>(a)...) {}
+};
 struct cu2rec_csr {
     DeviceCsr impl;
     template <class... A>
@@ -293,6 +336,30 @@ int cu2rec_sgd_update(const int *indptr, const int *indices, const float *data, 
         require(hyper, "cu2rec_sgd_update: hyper is null");
         sgd_update(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,
                    *hyper, seed, iter0, n_iters, mode, update_items, user_offset, as_stream(stream));
+    });
+}
+
+int cu2rec_schedule_create(const int *indptr, const int *indices, int n_rows, int n_cols, int nnz,
+                           cu2rec_schedule **out) {
+    return guarded([&] {
+        require(out, "out is null");
+        *out = nullptr;
+        *out = new cu2rec_schedule(indptr, indices, n_rows, n_cols, nnz);
+    });
+}
+
+void cu2rec_schedule_destroy(cu2rec_schedule *s) { delete s; }
+
+int cu2rec_sgd_update_ordered(cu2rec_schedule *schedule, const int *indptr, const int *indices, const float *data,
+                              int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
+                              float *item_bias, float global_bias, int n_factors, const cu2rec_hyper *hyper,
+                              uint64_t seed, uint64_t iter0, int n_iters, int update_items, int user_offset,
+                              void *stream) {
+    return guarded([&] {
+        require(schedule && hyper, "cu2rec_sgd_update_ordered: null argument");
+        sgd_update_ordered(schedule->impl, indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias,
+                           global_bias, n_factors, *hyper, seed, iter0, n_iters, update_items, user_offset,
+                           as_stream(stream));
     });
 }
 

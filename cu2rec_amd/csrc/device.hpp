@@ -5,17 +5,30 @@
 
 #include <cstdint>
 
+#include <memory>
+
 #include "hip_check.hpp"
+#include "ordered.hpp"
 
 struct cu2rec_csr;
 struct cu2rec_model;
 
 namespace cu2rec {
 
+// fills the launch argument block after validating shapes / alignment (shared by all SGD modes)
+SgdArgs make_sgd_args(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P,
+                      int ldp, float *Q, int ldq, float *user_bias, float *item_bias, float global_bias, int n_factors,
+                      const cu2rec_hyper &hyper, uint64_t seed, int update_items, int user_offset);
+
 void sgd_update(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P, int ldp,
                 float *Q, int ldq, float *user_bias, float *item_bias, float global_bias, int n_factors,
                 const cu2rec_hyper &hyper, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
                 int user_offset, hipStream_t stream);
+
+void sgd_update_ordered(OrderedSchedule &schedule, const int *indptr, const int *indices, const float *data,
+                        int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
+                        float *item_bias, float global_bias, int n_factors, const cu2rec_hyper &hyper, uint64_t seed,
+                        uint64_t iter0, int n_iters, int update_items, int user_offset, hipStream_t stream);
 
 void loss(const int *indptr, const int *indices, const float *data, int n_rows, int nnz, const float *P, int ldp,
           const float *Q, int ldq, const float *user_bias, const float *item_bias, float global_bias, int n_factors,
@@ -32,6 +45,7 @@ struct DeviceCsr {
     int rows, cols, nnz;
     int max_item;
     int users_with_ratings;
+    mutable std::unique_ptr<OrderedSchedule> schedule;  // created on first CU2REC_SGD_ORDERED use
 };
 
 // P, Q, biases on the device with padded rows (see include/cu2rec_amd.h "Device data layout").

@@ -20,96 +20,13 @@
 
 #include "kernels.hpp"
 #include "sampler.hpp"
+#include "sgd_device.hpp"
 
 namespace cu2rec {
 
 namespace {
 
-constexpr int kGroup = 16;                    // lanes per user: one DPP row
-constexpr int kBlock = 256;                   // threads per block: 4 wavefronts, 16 groups
-constexpr int kGroupsPerBlock = kBlock / kGroup;
-
-// ---- cross-lane sum inside a 16-lane row -------------------------------------------------
-template <int kCtrl>
-__device__ __forceinline__ float dpp_move(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, false));
-}
-
-// xor butterfly 1, 2, 4, 8.  After the quad steps every lane of a quad holds the quad's sum,
-// so mirroring inside 8 and then 16 lanes fetches exactly what the xor-4 / xor-8 partner holds.
-__device__ __forceinline__ float row_sum16(float v) {
-    v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
-    v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
-    v = v + dpp_move<0x141>(v);  // row_half_mirror
-    v = v + dpp_move<0x140>(v);  // row_mirror
-    return v;
-}
-
-// ---- factor rows -------------------------------------------------------------------------
-template <int J>
-struct Row {
-    float4 v[J];
-};
-
-template <int J>
-__device__ __forceinline__ Row<J> load_row(const float *__restrict__ base, size_t row, int ld, int nslots, int lane) {
-    const float4 *p = reinterpret_cast<const float4 *>(base + row * static_cast<size_t>(ld));
-    Row<J> r;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int slot = lane + kGroup * j;
-        r.v[j] = slot < nslots ? p[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    return r;
-}
-
-template <int J>
-__device__ __forceinline__ void store_row(float *__restrict__ base, size_t row, int ld, int nslots, int lane,
-                                          const Row<J> &r) {
-    float4 *p = reinterpret_cast<float4 *>(base + row * static_cast<size_t>(ld));
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int slot = lane + kGroup * j;
-        if (slot < nslots) p[slot] = r.v[j];
-    }
-}
-
-// util.cu:199-204 get_prediction, in the group's order: per-lane fmaf chain in slot order,
-// butterfly, then ((gb + ub) + ib) + dot.
-template <int J>
-__device__ __forceinline__ float predict(const Row<J> &p, const Row<J> &q, float ub, float ib, float gb) {
-    float acc = 0.f;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        acc = __builtin_fmaf(q.v[j].x, p.v[j].x, acc);
-        acc = __builtin_fmaf(q.v[j].y, p.v[j].y, acc);
-        acc = __builtin_fmaf(q.v[j].z, p.v[j].z, acc);
-        acc = __builtin_fmaf(q.v[j].w, p.v[j].w, acc);
-    }
-    const float dot = row_sum16(acc);
-    return ((gb + ub) + ib) + dot;
-}
-
-// mf_sequential.cu:133-136 on one float: new = old + lr * (err * other_old - reg * old)
-__device__ __forceinline__ float step(float old, float other_old, float err, float lr, float reg) {
-    return old + lr * (err * other_old - reg * old);
-}
-
-template <int J>
-__device__ __forceinline__ void rank1_update(Row<J> &p, Row<J> &q, float err, const SgdHyper &h) {
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const float4 po = p.v[j], qo = q.v[j];
-        p.v[j].x = step(po.x, qo.x, err, h.lr, h.p_reg);
-        p.v[j].y = step(po.y, qo.y, err, h.lr, h.p_reg);
-        p.v[j].z = step(po.z, qo.z, err, h.lr, h.p_reg);
-        p.v[j].w = step(po.w, qo.w, err, h.lr, h.p_reg);
-        q.v[j].x = step(qo.x, po.x, err, h.lr, h.q_reg);
-        q.v[j].y = step(qo.y, po.y, err, h.lr, h.q_reg);
-        q.v[j].z = step(qo.z, po.z, err, h.lr, h.q_reg);
-        q.v[j].w = step(qo.w, po.w, err, h.lr, h.q_reg);
-    }
-}
+using namespace dev;
 
 // One SGD update of user x at iteration `it` (sgd.cu:27-73 / mf_sequential.cu:104-142), p and
 // the user bias live in registers; the item row is read, updated and written back in place.

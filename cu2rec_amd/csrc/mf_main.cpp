@@ -25,7 +25,9 @@ int main(int argc, char **argv) {
                 config_path = optarg;
                 break;
             case 'm':
-                mode = std::strcmp(optarg, "serial") == 0 ? CU2REC_SGD_SERIAL : CU2REC_SGD_HOGWILD;
+                mode = std::strcmp(optarg, "serial") == 0    ? CU2REC_SGD_SERIAL
+                       : std::strcmp(optarg, "ordered") == 0 ? CU2REC_SGD_ORDERED
+                                                             : CU2REC_SGD_HOGWILD;
                 break;
             default:
                 std::cout << "Unknown option.\n";  // mf.cu:27-29

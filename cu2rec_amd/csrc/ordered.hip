@@ -1,0 +1,211 @@
+// Ordered SGD: the sequential semantics of mf_sequential.cu:102-143 at GPU speed, deterministic and
+// bit-identical to the CPU oracle (TREE16 dot order), with no races.
+//
+// Why it is possible: the sampler is counter based, so WHICH rating user x trains on at iteration i is a
+// pure function of (seed, x, i) -- known before any value is computed.  Inside one iteration every user
+// appears exactly once, so two updates conflict only through a shared ITEM row, and the sequential order
+// matters only among the users that sampled the same item.  Hence, per iteration:
+//     for every item in parallel:  apply the updates of the users that sampled it, in ascending user order
+// is exactly the sequential result.  An iteration becomes a set of independent "item chains".
+//
+// Pipeline for a batch of B iterations (B <= kMaxBatch):
+//   1. schedule_keys_kernel  one thread per (iteration b, user x): draw the rating, emit
+//        key = b << item_bits | popularity_rank(item)        (users without ratings: one bit above all keys)
+//        val = user << 32 | rating bits
+//   2. stable LSB radix sort of the (key, val) pairs (hipCUB/rocPRIM DeviceRadixSort; stability keeps users
+//      ascending inside a chain).  Afterwards iteration b occupies [b * n_active, (b+1) * n_active), chains are
+//      runs of equal keys, and because keys carry the item's popularity RANK, the longest chains come first.
+//   3. sgd_ordered_kernel, one launch per iteration (the kernel boundary carries the P-row dependency from
+//      iteration b to b+1): a 16-lane group owns a window of 4 sorted positions and runs every chain that
+//      STARTS in its window to its end, with the item row and item bias held in registers for the whole chain
+//      (the item row is read and written once per chain, not once per update).
+// The arithmetic of one update is the same device code as the Hogwild kernel (sgd_device.hpp).
+#include <hip/hip_runtime.h>
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "hip_check.hpp"
+#include "kernels.hpp"
+#include "ordered.hpp"
+#include "sampler.hpp"
+#include "sgd_device.hpp"
+
+namespace cu2rec {
+
+namespace {
+
+using namespace dev;
+
+constexpr int kWindow = 4;  // sorted positions per group
+
+__global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__restrict__ indptr,
+                                                               const int *__restrict__ indices,
+                                                               const float *__restrict__ data,
+                                                               const int *__restrict__ item_rank, int n_rows,
+                                                               int n_batch, int item_bits, uint32_t sentinel,
+                                                               uint64_t seed, uint64_t iter0, int user_offset,
+                                                               uint32_t *__restrict__ keys, uint64_t *__restrict__ vals) {
+    const size_t total = static_cast<size_t>(n_rows) * n_batch;
+    for (size_t idx = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; idx < total;
+         idx += static_cast<size_t>(gridDim.x) * kBlock) {
+        const int b = static_cast<int>(idx / n_rows);
+        const int x = static_cast<int>(idx - static_cast<size_t>(b) * n_rows);
+        const int low = indptr[x], high = indptr[x + 1];
+        uint32_t key = sentinel;
+        uint64_t val = 0;
+        if (low != high) {
+            const int y_i = sampler_index(seed, static_cast<uint64_t>(user_offset + x), iter0 + b, low, high);
+            const int y = indices[y_i];
+            key = (static_cast<uint32_t>(b) << item_bits) | static_cast<uint32_t>(item_rank[y]);
+            val = (static_cast<uint64_t>(static_cast<uint32_t>(x)) << 32) | __float_as_uint(data[y_i]);
+        }
+        keys[idx] = key;
+        vals[idx] = val;
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const uint32_t *__restrict__ keys,
+                                                             const uint64_t *__restrict__ vals, int n_active,
+                                                             const int *__restrict__ item_of_rank,
+                                                             uint32_t item_mask) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
+    const int w0 = group * kWindow;
+    for (int t = 0; t < kWindow; ++t) {
+        const int start = w0 + t;
+        if (start >= n_active) break;
+        const uint32_t key = keys[start];
+        if (start > 0 && keys[start - 1] == key) continue;  // the chain began in an earlier window
+        const int y = item_of_rank[key & item_mask];
+        Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
+        float ib = a.item_bias[y];
+        int s = start;
+        uint64_t val = vals[s];
+        bool more;
+        do {
+            const int x = static_cast<int>(val >> 32);
+            const float rating = __uint_as_float(static_cast<uint32_t>(val));
+            Row<J> p = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+            const float ub = a.user_bias[x];
+            // look ahead while the row is in flight
+            ++s;
+            more = s < n_active && keys[s] == key;
+            if (more) val = vals[s];
+            const float err = rating - predict<J>(p, q, ub, ib, a.global_bias);
+            rank1_update<J>(p, q, err, a.h);
+            store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
+            if (lane == 0) a.user_bias[x] = ub + a.h.lr * (err - a.h.ub_reg * ub);
+            ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
+        } while (more);
+        store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
+        if (lane == 0) a.item_bias[y] = ib;
+    }
+}
+
+template <int J>
+void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
+                  uint32_t item_mask, hipStream_t stream) {
+    const int groups = (n_active + kWindow - 1) / kWindow;
+    const int blocks = (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
+    hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,
+                       item_of_rank, item_mask);
+}
+
+int bits_for(int n) {  // bits needed to represent values in [0, n)
+    int b = 1;
+    while ((1ll << b) < n) ++b;
+    return b;
+}
+
+}  // namespace
+
+OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int n_rows_, int n_cols_, int nnz_)
+    : n_rows(n_rows_), n_cols(n_cols_), nnz(nnz_) {
+    require(d_indptr && n_rows >= 0 && n_cols > 0 && nnz >= 0, "ordered schedule: bad argument");
+    require_device();
+    // one-off host pass: users with ratings, item popularity rank (descending rating count, ties by item id)
+    std::vector<int> indptr(static_cast<size_t>(n_rows) + 1), indices(static_cast<size_t>(std::max(nnz, 1)));
+    CU2REC_HIP(hipMemcpy(indptr.data(), d_indptr, indptr.size() * sizeof(int), hipMemcpyDeviceToHost));
+    if (nnz) CU2REC_HIP(hipMemcpy(indices.data(), d_indices, static_cast<size_t>(nnz) * sizeof(int), hipMemcpyDeviceToHost));
+    n_active = 0;
+    for (int u = 0; u < n_rows; ++u) n_active += indptr[u + 1] > indptr[u];
+    std::vector<int> count(n_cols, 0), order(n_cols), rank(n_cols);
+    for (int k = 0; k < nnz; ++k) {
+        require(indices[k] >= 0 && indices[k] < n_cols, "ordered schedule: item id out of range");
+        ++count[indices[k]];
+    }
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int l, int r) { return count[l] > count[r]; });
+    for (int r = 0; r < n_cols; ++r) rank[order[r]] = r;
+    item_rank.allocate(n_cols);
+    item_rank.upload(rank.data(), n_cols);
+    item_of_rank.allocate(n_cols);
+    item_of_rank.upload(order.data(), n_cols);
+    item_bits = bits_for(n_cols);
+    // batch size: keep key = b << item_bits | rank (+ the sentinel bit) inside 32 bits and the buffers modest
+    int b_bits = std::min(6, 31 - item_bits - 1);
+    require(b_bits >= 0, "ordered schedule: too many items for 32-bit keys");
+    max_batch = 1 << b_bits;
+    while (max_batch > 1 && static_cast<size_t>(max_batch) * n_rows > (size_t(1) << 27)) max_batch >>= 1;
+    const size_t cap = static_cast<size_t>(max_batch) * std::max(n_rows, 1);
+    keys[0].allocate(cap);
+    keys[1].allocate(cap);
+    vals[0].allocate(cap);
+    vals[1].allocate(cap);
+    hipcub::DoubleBuffer<uint32_t> dk(keys[0].ptr, keys[1].ptr);
+    hipcub::DoubleBuffer<uint64_t> dv(vals[0].ptr, vals[1].ptr);
+    temp_bytes = 0;
+    CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, dk, dv, static_cast<int>(cap), 0, 32, nullptr));
+    temp.allocate(temp_bytes + 16);
+}
+
+void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream) {
+    if (n_active == 0) return;
+    const uint32_t item_mask = (1u << item_bits) - 1u;
+    int done = 0;
+    while (done < n_iters) {
+        const int nb = std::min(max_batch, n_iters - done);
+        const int b_bits = bits_for(nb);
+        const uint32_t sentinel = 1u << (item_bits + b_bits);
+        const size_t n = static_cast<size_t>(nb) * n_rows;
+        const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 1 << 16));
+        hipLaunchKernelGGL(schedule_keys_kernel, dim3(blocks), dim3(kBlock), 0, stream, a.indptr, a.indices, a.data,
+                           item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, iter0 + done, a.user_offset,
+                           keys[0].ptr, vals[0].ptr);
+        CU2REC_HIP(hipGetLastError());
+        hipcub::DoubleBuffer<uint32_t> dk(keys[0].ptr, keys[1].ptr);
+        hipcub::DoubleBuffer<uint64_t> dv(vals[0].ptr, vals[1].ptr);
+        size_t bytes = temp_bytes;
+        CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(temp.ptr, bytes, dk, dv, static_cast<int>(n), 0,
+                                                      item_bits + b_bits + 1, stream));
+        const uint32_t *sk = dk.Current();
+        const uint64_t *sv = dv.Current();
+        a.iters = 1;
+        for (int b = 0; b < nb; ++b) {
+            a.iter0 = iter0 + done + b;
+            const uint32_t *kb = sk + static_cast<size_t>(b) * n_active;
+            const uint64_t *vb = sv + static_cast<size_t>(b) * n_active;
+            switch (slots_per_lane(a.nslots)) {
+                case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
+                case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
+                case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
+                case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
+                case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
+                case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
+                case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
+                case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
+                default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
+            }
+        }
+        CU2REC_HIP(hipGetLastError());
+        done += nb;
+        // the next batch reuses the key / value buffers: the stream orders it behind this batch's kernels
+    }
+}
+
+}  // namespace cu2rec

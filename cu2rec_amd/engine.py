@@ -28,6 +28,13 @@ class DeviceRatings:
         self.indices = torch.from_numpy(host.indices if host.nnz else np.zeros(1, np.int32)).to(device)
         self.data = torch.from_numpy(host.data if host.nnz else np.zeros(1, np.float32)).to(device)
         self.global_bias = host.global_bias
+        self._schedule = None
+
+    def schedule(self):
+        """Ordered-mode workspace for this CSR, created on first use."""
+        if self._schedule is None:
+            self._schedule = api.Schedule(self.indptr.data_ptr(), self.indices.data_ptr(), self.rows, self.cols, self.nnz)
+        return self._schedule
 
 
 class Engine:
@@ -66,6 +73,13 @@ class Engine:
     # ---- hot path -------------------------------------------------------------------------
     def sgd(self, ratings, hyper, seed, iter0, n_iters, mode=api.SGD_HOGWILD, update_items=True, user_offset=0):
         assert ratings.rows <= self.rows and ratings.cols <= self.cols
+        if api._mode(mode) == api.SGD_ORDERED:
+            api.sgd_update_ordered(ratings.schedule(), ratings.indptr.data_ptr(), ratings.indices.data_ptr(),
+                                   ratings.data.data_ptr(), ratings.rows, self.cols, self.P.data_ptr(), self.ld,
+                                   self.Q.data_ptr(), self.ld, self.user_bias.data_ptr(), self.item_bias.data_ptr(),
+                                   self.global_bias, self.f, hyper, seed, iter0, n_iters, update_items, user_offset,
+                                   _stream_ptr())
+            return
         api.sgd_update(ratings.indptr.data_ptr(), ratings.indices.data_ptr(), ratings.data.data_ptr(), ratings.rows,
                        self.cols, self.P.data_ptr(), self.ld, self.Q.data_ptr(), self.ld, self.user_bias.data_ptr(),
                        self.item_bias.data_ptr(), self.global_bias, self.f, hyper, seed, iter0, n_iters, mode,

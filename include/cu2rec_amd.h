@@ -139,7 +139,13 @@ typedef enum cu2rec_sgd_mode {
     /* One group walks the users in ascending order: mf_sequential.cu:102-143 exactly
      * (in-place Gauss-Seidel).  Bit-identical to the CPU oracle in its TREE16 dot order.
      * For parity tests; orders of magnitude slower. */
-    CU2REC_SGD_SERIAL = 1
+    CU2REC_SGD_SERIAL = 1,
+    /* The sequential result at GPU speed, deterministic, no races: the sample stream is value independent,
+     * so each iteration is scheduled ahead of time as independent per-item chains whose updates run in
+     * ascending user order with the item row held in registers (cu2rec_amd/csrc/ordered.hip).
+     * Bit-identical to CU2REC_SGD_SERIAL and to the CPU oracle.  Needs a cu2rec_schedule workspace
+     * (the object layer creates one per cu2rec_csr on first use). */
+    CU2REC_SGD_ORDERED = 2
 } cu2rec_sgd_mode;
 
 /* Replaces sgd_update (sgd.cu:22-75) + the per-iteration launch loop of train()
@@ -151,6 +157,19 @@ int cu2rec_sgd_update(const int *indptr, const int *indices, const float *data, 
                       float *P, int ldp, float *Q, int ldq, float *user_bias, float *item_bias, float global_bias,
                       int n_factors, const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters,
                       int mode, int update_items, int user_offset, void *stream);
+
+/* Workspace of CU2REC_SGD_ORDERED for one device CSR: item popularity ranks, key/value buffers of the
+ * per-iteration schedule, sort scratch.  indptr / indices are device pointers (read once at creation). */
+typedef struct cu2rec_schedule cu2rec_schedule;
+int cu2rec_schedule_create(const int *indptr, const int *indices, int n_rows, int n_cols, int nnz,
+                           cu2rec_schedule **out);
+void cu2rec_schedule_destroy(cu2rec_schedule *s);
+/* cu2rec_sgd_update in CU2REC_SGD_ORDERED mode on raw device pointers (same arguments + the workspace). */
+int cu2rec_sgd_update_ordered(cu2rec_schedule *schedule, const int *indptr, const int *indices, const float *data,
+                              int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
+                              float *item_bias, float global_bias, int n_factors, const cu2rec_hyper *hyper,
+                              uint64_t seed, uint64_t iter0, int n_iters, int update_items, int user_offset,
+                              void *stream);
 
 /* Replaces calculate_loss_gpu + get_error_metrics_gpu (loss.cu:19-49,150-200) in ONE pass:
  * residual e = r - (gb + ub + ib + p.q) per rating, sum |e| and sum e^2 accumulated in

@@ -294,3 +294,87 @@ def test_ml1m_shape_properties():
         last = cur
     for a in model.download():
         assert np.isfinite(a).all()
+
+
+# ------------------------------------------------------------------ SGD, ordered: the sequential result, in parallel
+
+@pytest.mark.parametrize("f,iters", [(1, 5), (10, 150), (50, 20), (100, 70), (128, 5), (300, 3)])
+def test_sgd_ordered_bit_exact_vs_oracle(f, iters):
+    # 300 users x 120 items: every iteration has long item chains; 150 and 70 cross the 64-iteration batches
+    tr, _ = _small_set()
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    model.sgd(cu.DeviceCSR(tr), HYPER, seed=42, iter0=0, n_iters=iters, mode="ordered")
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, iters, dot_order=orc.DOT_TREE16)
+    for name, g, w in zip("P Q ub ib".split(), model.download(), (P, Q, ub, ib)):
+        np.testing.assert_array_equal(g, w, err_msg=name)
+
+
+def test_sgd_ordered_resume_empty_users_and_frozen_items():
+    m = _toy("toy_missing_user.csv")  # user 2 has no ratings: sentinel keys in the schedule
+    f = 10
+    P, Q, ub, ib = orc.init_model(m.rows, m.cols, f)
+    model = cu.Model(m.rows, m.cols, f, m.global_bias)
+    d = cu.DeviceCSR(m)
+    model.sgd(d, HYPER, 9, 0, 3, mode="ordered")
+    model.sgd(d, HYPER, 9, 3, 70, mode="ordered")
+    orc.sgd_iterations(_as_orc(m), P, Q, ub, ib, m.global_bias, HYPER, 9, 0, 73, dot_order=orc.DOT_TREE16)
+    for g, w in zip(model.download(), (P, Q, ub, ib)):
+        np.testing.assert_array_equal(g, w)
+    model.sgd(d, HYPER, 9, 73, 5, mode="ordered", update_items=False)
+    orc.sgd_iterations(_as_orc(m), P, Q, ub, ib, m.global_bias, HYPER, 9, 73, 5, dot_order=orc.DOT_TREE16,
+                       update_items=False)
+    for g, w in zip(model.download(), (P, Q, ub, ib)):
+        np.testing.assert_array_equal(g, w)
+
+
+def test_sgd_ordered_engine_user_offset():
+    """Raw-pointer entry point with a sharded user range: draws are keyed by the global user id."""
+    from cu2rec_amd.engine import DeviceRatings, Engine
+    tr, _ = _small_set(seed=8)
+    f, u0, u1 = 20, 100, 260
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    shard = tr.slice_users(u0, u1)
+    eng = Engine(u1 - u0, tr.cols, f, tr.global_bias, P[u0:u1], Q, ub[u0:u1], ib)
+    eng.sgd(DeviceRatings(shard, eng.device), HYPER, 42, 0, 12, mode="ordered", user_offset=u0)
+    # oracle: the same users inside the full matrix, everyone else without ratings
+    indptr = tr.indptr.copy()
+    indptr[:u0 + 1] = tr.indptr[u0]
+    indptr[u1:] = tr.indptr[u1]
+    masked = orc.CSR(indptr, tr.indices, tr.data, tr.rows, tr.cols)
+    orc.sgd_iterations(masked, P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, 12, dot_order=orc.DOT_TREE16)
+    gP, gQ, gub, gib = eng.download()
+    np.testing.assert_array_equal(gP, P[u0:u1])
+    np.testing.assert_array_equal(gQ, Q)
+    np.testing.assert_array_equal(gub, ub[u0:u1])
+    np.testing.assert_array_equal(gib, ib)
+
+
+def test_ordered_full_size_ml1m_and_ml20m_bit_exact():
+    """BASELINE.json configs[1] and [2] at full size: the ordered GPU schedule against the sequential CPU
+    oracle, every parameter bit for bit (ML-1M shape f=50, 100 iterations; ML-20M shape f=100, 8 iterations)."""
+    import bench
+    for name, f, iters in (("ml-1m", 50, 100), ("ml-20m", 100, 8)):
+        tr, te = bench.load_dataset(name, 20240917, 0, lambda: None)
+        P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+        model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+        model.sgd(cu.DeviceCSR(tr), HYPER, 42, 0, iters, mode="ordered")
+        orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, iters, dot_order=orc.DOT_TREE16)
+        gP, gQ, gub, gib = model.download()
+        np.testing.assert_array_equal(gQ, Q, err_msg=name)
+        np.testing.assert_array_equal(gP, P, err_msg=name)
+        np.testing.assert_array_equal(gub, ub, err_msg=name)
+        np.testing.assert_array_equal(gib, ib, err_msg=name)
+        got = model.loss(cu.DeviceCSR(te))
+        want = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_TREE16)
+        assert got["rmse"] == want["rmse"] and got["mae"] == want["mae"]
+
+
+def test_train_ordered_equals_serial():
+    tr, te = _small_set(seed=6)
+    outs = []
+    for mode in ("serial", "ordered"):
+        cfg = cu.default_config(total_iterations=30, n_factors=12, check_error=10, learning_rate=0.02)
+        outs.append(cu.train(tr, te, cfg, mode=mode, verbose=False))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
