@@ -40,7 +40,8 @@ namespace {
 
 using namespace dev;
 
-constexpr int kWindow = 4;  // sorted positions per group
+constexpr int kWindow = 4;     // sorted positions per group (regular chains)
+constexpr int kHotChains = 256;  // most popular items: one group each, tile-prefetched (see sgd_ordered_kernel)
 
 __global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__restrict__ indptr,
                                                                const int *__restrict__ indices,
@@ -68,19 +69,122 @@ __global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__rest
     }
 }
 
+// ---- one update inside a chain: the user's row comes in, the item row / bias stay in registers -------------
+template <int J>
+__device__ __forceinline__ float chain_step(const SgdArgs &a, Row<J> &p, Row<J> &q, float ub, float &ib, float rating) {
+    const float err = rating - predict<J>(p, q, ub, ib, a.global_bias);  // sgd.cu:45
+    rank1_update<J>(p, q, err, a.h);                                      // mf_sequential.cu:129-137
+    ib = ib + a.h.lr * (err - a.h.ib_reg * ib);                           // :141
+    return ub + a.h.lr * (err - a.h.ub_reg * ub);                         // :140 (new user bias)
+}
+
+// T consecutive chain entries with their user rows in registers (lane t < n also holds entry t's value / bias)
+template <int J, int T>
+struct Tile {
+    Row<J> rows[T];
+    uint64_t val;  // lane t: (user << 32 | rating bits) of entry t
+    float ub;      // lane t: user_bias of entry t
+    int n;
+};
+
+template <int J, int T>
+__device__ __forceinline__ void load_tile(Tile<J, T> &tile, const SgdArgs &a, const uint64_t *__restrict__ vals, int s,
+                                          int end, int lane) {
+    tile.n = min(T, end - s);
+    tile.val = lane < tile.n ? vals[s + lane] : 0ull;
+    const int my_user = static_cast<int>(tile.val >> 32);
+    tile.ub = lane < tile.n ? a.user_bias[my_user] : 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (t < tile.n) {
+            const int x = __shfl(my_user, t, kGroup);
+            tile.rows[t] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+        }
+    }
+}
+
+template <int J, int T>
+__device__ __forceinline__ void run_tile(Tile<J, T> &tile, const SgdArgs &a, Row<J> &q, float &ib, int lane) {
+    const int my_user = static_cast<int>(tile.val >> 32);
+    const float my_rating = __uint_as_float(static_cast<uint32_t>(tile.val));
+    float my_new_ub = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (t < tile.n) {
+            const int x = __shfl(my_user, t, kGroup);
+            const float rating = __shfl(my_rating, t, kGroup);
+            const float ub = __shfl(tile.ub, t, kGroup);
+            const float new_ub = chain_step<J>(a, tile.rows[t], q, ub, ib, rating);
+            store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, tile.rows[t]);
+            if (lane == t) my_new_ub = new_ub;
+        }
+    }
+    if (lane < tile.n) a.user_bias[my_user] = my_new_ub;
+}
+
+// first position in keys[0, n) whose key is >= target
+__device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys, int n, uint32_t target) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <int J>
+struct HotTile {
+    static constexpr int value = J <= 2 ? 4 : (J <= 4 ? 2 : 1);
+};
+
+// One launch = one iteration.  Two roles, chosen per block:
+//  * blocks [0, hot_blocks): one group per popularity rank r < n_hot.  These are the long chains (thousands of
+//    updates on the most rated items); the chain is the critical path of the iteration, so its user rows are
+//    fetched a tile ahead (double buffered in registers) and only arithmetic stays on the dependent path.
+//  * the other blocks: a group owns a window of kWindow sorted positions and runs every chain of rank >= n_hot
+//    that STARTS in its window (chains are short there; one row of look-ahead).
 template <int J>
 __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const uint32_t *__restrict__ keys,
                                                              const uint64_t *__restrict__ vals, int n_active,
                                                              const int *__restrict__ item_of_rank,
-                                                             uint32_t item_mask) {
+                                                             uint32_t item_mask, uint32_t key_base, int n_hot,
+                                                             int hot_blocks) {
     const int lane = threadIdx.x & (kGroup - 1);
-    const int group = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
+    if (static_cast<int>(blockIdx.x) < hot_blocks) {
+        constexpr int T = HotTile<J>::value;
+        const int r = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
+        if (r >= n_hot) return;
+        const int begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
+        const int end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));  // r+1 <= item_mask
+        if (begin >= end) return;
+        const int y = item_of_rank[r];
+        Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
+        float ib = a.item_bias[y];
+        Tile<J, T> ta, tb;
+        int s = begin;
+        load_tile<J, T>(ta, a, vals, s, end, lane);
+        while (true) {
+            if (s + T < end) load_tile<J, T>(tb, a, vals, s + T, end, lane);
+            run_tile<J, T>(ta, a, q, ib, lane);
+            s += T;
+            if (s >= end) break;
+            if (s + T < end) load_tile<J, T>(ta, a, vals, s + T, end, lane);
+            run_tile<J, T>(tb, a, q, ib, lane);
+            s += T;
+            if (s >= end) break;
+        }
+        store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
+        if (lane == 0) a.item_bias[y] = ib;
+        return;
+    }
+    const int group = ((blockIdx.x - hot_blocks) * kBlock + threadIdx.x) / kGroup;
     const int w0 = group * kWindow;
     for (int t = 0; t < kWindow; ++t) {
         const int start = w0 + t;
         if (start >= n_active) break;
         const uint32_t key = keys[start];
-        if (start > 0 && keys[start - 1] == key) continue;  // the chain began in an earlier window
+        if (static_cast<int>(key & item_mask) < n_hot) continue;  // a hot chain: the other role runs it
+        if (start > 0 && keys[start - 1] == key) continue;        // the chain began in an earlier window
         const int y = item_of_rank[key & item_mask];
         Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
         float ib = a.item_bias[y];
@@ -96,11 +200,9 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
             ++s;
             more = s < n_active && keys[s] == key;
             if (more) val = vals[s];
-            const float err = rating - predict<J>(p, q, ub, ib, a.global_bias);
-            rank1_update<J>(p, q, err, a.h);
+            const float new_ub = chain_step<J>(a, p, q, ub, ib, rating);
             store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
-            if (lane == 0) a.user_bias[x] = ub + a.h.lr * (err - a.h.ub_reg * ub);
-            ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
+            if (lane == 0) a.user_bias[x] = new_ub;
         } while (more);
         store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
         if (lane == 0) a.item_bias[y] = ib;
@@ -109,11 +211,12 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
 
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
-                  uint32_t item_mask, hipStream_t stream) {
+                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream) {
+    const int hot_blocks = (n_hot + kGroupsPerBlock - 1) / kGroupsPerBlock;
     const int groups = (n_active + kWindow - 1) / kWindow;
-    const int blocks = (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
+    const int blocks = hot_blocks + (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
     hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,
-                       item_of_rank, item_mask);
+                       item_of_rank, item_mask, key_base, n_hot, hot_blocks);
 }
 
 int bits_for(int n) {  // bits needed to represent values in [0, n)
@@ -167,6 +270,8 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
 void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream) {
     if (n_active == 0) return;
     const uint32_t item_mask = (1u << item_bits) - 1u;
+    // ranks [0, n_hot) get a dedicated group each with deep prefetch; keep r + 1 representable in item_bits
+    const int n_hot = std::min(std::min(n_cols, kHotChains), static_cast<int>(item_mask));
     int done = 0;
     while (done < n_iters) {
         const int nb = std::min(max_batch, n_iters - done);
@@ -190,15 +295,16 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             a.iter0 = iter0 + done + b;
             const uint32_t *kb = sk + static_cast<size_t>(b) * n_active;
             const uint64_t *vb = sv + static_cast<size_t>(b) * n_active;
+            const uint32_t key_base = static_cast<uint32_t>(b) << item_bits;
             switch (slots_per_lane(a.nslots)) {
-                case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
-                case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
-                case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
-                case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
-                case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
-                case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
-                case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
-                case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, stream); break;
+                case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
+                case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
+                case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
+                case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
+                case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
+                case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
+                case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
+                case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
                 default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
             }
         }
