@@ -78,48 +78,69 @@ __device__ __forceinline__ float chain_step(const SgdArgs &a, Row<J> &p, Row<J> 
     return ub + a.h.lr * (err - a.h.ub_reg * ub);                         // :140 (new user bias)
 }
 
-// T consecutive chain entries with their user rows in registers (lane t < n also holds entry t's value / bias)
-template <int J, int T>
-struct Tile {
-    Row<J> rows[T];
-    uint64_t val;  // lane t: (user << 32 | rating bits) of entry t
-    float ub;      // lane t: user_bias of entry t
-    int n;
+// ---- hot chains: 16-entry chunks, user rows fetched one tile ahead -----------------------------------------
+// Everything here is branch free on purpose: with straight-line code the compiler keeps the next tile's row
+// loads (and the next chunk's entry / bias loads) in flight behind counted s_waitcnt while the current tile
+// computes; with per-entry predicates it falls back to s_waitcnt vmcnt(0) after every load.
+
+// entry (user << 32 | rating bits) and user bias of 16 consecutive chain entries, one per lane
+struct ChunkMeta {
+    uint64_t val;
+    float ub;
 };
 
+__device__ __forceinline__ ChunkMeta load_meta(const SgdArgs &a, const uint64_t *__restrict__ vals, int s, int lane) {
+    ChunkMeta m;
+    m.val = vals[s + lane];
+    m.ub = a.user_bias[static_cast<int>(m.val >> 32)];
+    return m;
+}
+
+// row load without control flow: lanes whose slot is past the row read the row's last slot and discard it
+template <int J>
+__device__ __forceinline__ Row<J> load_row_nb(const float *__restrict__ base, size_t row, int ld, int nslots, int lane) {
+    const float4 *p = reinterpret_cast<const float4 *>(base + row * static_cast<size_t>(ld));
+    Row<J> r;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int slot = lane + kGroup * j;
+        const float4 v = p[min(slot, nslots - 1)];
+        const bool ok = slot < nslots;
+        r.v[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    return r;
+}
+
 template <int J, int T>
-__device__ __forceinline__ void load_tile(Tile<J, T> &tile, const SgdArgs &a, const uint64_t *__restrict__ vals, int s,
-                                          int end, int lane) {
-    tile.n = min(T, end - s);
-    tile.val = lane < tile.n ? vals[s + lane] : 0ull;
-    const int my_user = static_cast<int>(tile.val >> 32);
-    tile.ub = lane < tile.n ? a.user_bias[my_user] : 0.f;
+struct RowTile {
+    Row<J> rows[T];
+};
+
+// rows of entries [first, first + T) of the chunk described by m
+template <int J, int T>
+__device__ __forceinline__ void load_rows(RowTile<J, T> &tile, const SgdArgs &a, const ChunkMeta &m, int first, int lane) {
+    const int my_user = static_cast<int>(m.val >> 32);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        if (t < tile.n) {
-            const int x = __shfl(my_user, t, kGroup);
-            tile.rows[t] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
-        }
+        const int x = __shfl(my_user, first + t, kGroup);
+        tile.rows[t] = load_row_nb<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
     }
 }
 
 template <int J, int T>
-__device__ __forceinline__ void run_tile(Tile<J, T> &tile, const SgdArgs &a, Row<J> &q, float &ib, int lane) {
-    const int my_user = static_cast<int>(tile.val >> 32);
-    const float my_rating = __uint_as_float(static_cast<uint32_t>(tile.val));
-    float my_new_ub = 0.f;
+__device__ __forceinline__ void run_rows(RowTile<J, T> &tile, const SgdArgs &a, const ChunkMeta &m, int first,
+                                         Row<J> &q, float &ib, float &my_new_ub, int lane) {
+    const int my_user = static_cast<int>(m.val >> 32);
+    const float my_rating = __uint_as_float(static_cast<uint32_t>(m.val));
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        if (t < tile.n) {
-            const int x = __shfl(my_user, t, kGroup);
-            const float rating = __shfl(my_rating, t, kGroup);
-            const float ub = __shfl(tile.ub, t, kGroup);
-            const float new_ub = chain_step<J>(a, tile.rows[t], q, ub, ib, rating);
-            store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, tile.rows[t]);
-            if (lane == t) my_new_ub = new_ub;
-        }
+        const int x = __shfl(my_user, first + t, kGroup);
+        const float rating = __shfl(my_rating, first + t, kGroup);
+        const float ub = __shfl(m.ub, first + t, kGroup);
+        const float new_ub = chain_step<J>(a, tile.rows[t], q, ub, ib, rating);
+        store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, tile.rows[t]);
+        my_new_ub = lane == first + t ? new_ub : my_new_ub;
     }
-    if (lane < tile.n) a.user_bias[my_user] = my_new_ub;
 }
 
 // first position in keys[0, n) whose key is >= target
@@ -160,18 +181,49 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
         const int y = item_of_rank[r];
         Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
         float ib = a.item_bias[y];
-        Tile<J, T> ta, tb;
+        const int n_chunks = (end - begin) / kGroup;
         int s = begin;
-        load_tile<J, T>(ta, a, vals, s, end, lane);
-        while (true) {
-            if (s + T < end) load_tile<J, T>(tb, a, vals, s + T, end, lane);
-            run_tile<J, T>(ta, a, q, ib, lane);
-            s += T;
-            if (s >= end) break;
-            if (s + T < end) load_tile<J, T>(ta, a, vals, s + T, end, lane);
-            run_tile<J, T>(tb, a, q, ib, lane);
-            s += T;
-            if (s >= end) break;
+        if (n_chunks > 0) {
+            const int last_chunk = begin + (n_chunks - 1) * kGroup;
+            RowTile<J, T> ra, rb;
+            ChunkMeta cur = load_meta(a, vals, s, lane);
+            load_rows<J, T>(ra, a, cur, 0, lane);
+            for (int c = 0; c < n_chunks; ++c) {
+                // next chunk's entries and biases: issued a whole chunk before they are needed
+                const ChunkMeta nxt = load_meta(a, vals, min(s + kGroup, last_chunk), lane);
+                float my_new_ub = 0.f;
+                if constexpr (T == 4) {
+                    load_rows<J, T>(rb, a, cur, 4, lane);
+                    run_rows<J, T>(ra, a, cur, 0, q, ib, my_new_ub, lane);
+                    load_rows<J, T>(ra, a, cur, 8, lane);
+                    run_rows<J, T>(rb, a, cur, 4, q, ib, my_new_ub, lane);
+                    load_rows<J, T>(rb, a, cur, 12, lane);
+                    run_rows<J, T>(ra, a, cur, 8, q, ib, my_new_ub, lane);
+                    load_rows<J, T>(ra, a, nxt, 0, lane);  // last chunk: a discarded re-load
+                    run_rows<J, T>(rb, a, cur, 12, q, ib, my_new_ub, lane);
+                } else {
+#pragma unroll
+                    for (int first = 0; first < kGroup; first += 2 * T) {
+                        load_rows<J, T>(rb, a, cur, first + T, lane);
+                        run_rows<J, T>(ra, a, cur, first, q, ib, my_new_ub, lane);
+                        if (first + 2 * T < kGroup) load_rows<J, T>(ra, a, cur, first + 2 * T, lane);
+                        else load_rows<J, T>(ra, a, nxt, 0, lane);
+                        run_rows<J, T>(rb, a, cur, first + T, q, ib, my_new_ub, lane);
+                    }
+                }
+                a.user_bias[static_cast<int>(cur.val >> 32)] = my_new_ub;  // 16 users, one store
+                cur = nxt;
+                s += kGroup;
+            }
+        }
+        for (; s < end; ++s) {  // fewer than 16 entries left
+            const uint64_t val = vals[s];
+            const int x = static_cast<int>(val >> 32);
+            Row<J> p = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+            const float ub = a.user_bias[x];
+            const float new_ub = chain_step<J>(a, p, q, ub, ib, __uint_as_float(static_cast<uint32_t>(val)));
+            store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
+            if (lane == 0) a.user_bias[x] = new_ub;
         }
         store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
         if (lane == 0) a.item_bias[y] = ib;
