@@ -102,6 +102,27 @@ def cpu_baseline(train, test, f, hyper, budget_s=12.0):
     return out
 
 
+def measured_traffic(workload, f, mode):
+    """HBM bytes per launch of the SGD kernel from the committed rocprofv3 PMC passes (profiles/), priced as
+    MI355X_MICROARCH.md prescribes (separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE doubled on
+    gfx950).  Counters cannot be read from inside this process, so the figure is the latest committed one for
+    this exact workload / kernel; None if there is none."""
+    import glob
+    name = {"hogwild": "sgd_hogwild_kernel", "ordered": "sgd_ordered_kernel", "serial": "sgd_serial_kernel"}[mode]
+    tag = "%s_f%d" % (workload.replace("-", ""), f)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % tag)), reverse=True):
+        try:
+            for kernel, k in json.load(open(path)).items():
+                if name in kernel and "hbm_bytes_per_launch_corrected" in k:
+                    return {"bytes_per_launch": k["hbm_bytes_per_launch_corrected"],
+                            "source": os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                      "passes; raw %.1f MB, FETCH_SIZE x2 gfx950 correction applied)"
+                                      % (k["hbm_bytes_per_launch_raw"] / 1e6)}
+        except (OSError, ValueError):
+            continue
+    return None
+
+
 def log(msg):
     sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - T_START, msg))
     sys.stderr.flush()
@@ -127,6 +148,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20240917)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-samples", type=int, default=200)
+    ap.add_argument("--ordered-steps", type=int, default=128,
+                    help="extra (untimed for `value`) pass in the exact ordered mode, reported beside the headline; 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -205,6 +228,24 @@ def main():
 
     log("kernel avg %.2f us (min %.2f us)" % (1e3 * kernel_ms, 1e3 * kernel_ms_min))
     final = job.loss(d_test)
+    final_iterations = it
+
+    # ---- the exact mode beside it: same data, fresh model, sequential semantics (bit-identical to the CPU oracle)
+    ordered = None
+    if world == 1 and args.ordered_steps > 0 and args.mode != "ordered":
+        eng_o = Engine(train.rows, train.cols, f, train.global_bias, device=device)
+        eng_o.sgd(d_train, hyper, 42, 0, 64, cu.SGD_ORDERED)  # warm-up incl. schedule workspace creation
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng_o.sgd(d_train, hyper, 42, 64, args.ordered_steps, cu.SGD_ORDERED)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        ordered = {"mode": "ordered (sequential semantics, deterministic; bit-identical to the CPU oracle in tests)",
+                   "value": users_active * args.ordered_steps / dt, "unit": "updates/s",
+                   "ms_per_step": 1e3 * dt / args.ordered_steps, "steps": args.ordered_steps,
+                   "test_rmse": eng_o.loss(d_test)["rmse"], "iterations_run": 64 + args.ordered_steps}
+        log("ordered mode: %.3f ms/step" % ordered["ms_per_step"])
+        del eng_o
     bytes_per_update = 16 * f + 32
     alg_bytes = users_active * bytes_per_update
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -220,13 +261,19 @@ def main():
                                                                          test.nnz, f, args.mode),
                        "updates_per_step_per_gpu": users_active, "sync_every": sync_every if world > 1 else None,
                        "merge": args.merge if world > 1 else None, "exchanges": job.exchanges},
-            "test_rmse": final["rmse"], "test_rmse_initial": rmse0, "iterations_run": it,
+            "test_rmse": final["rmse"], "test_rmse_initial": rmse0, "iterations_run": final_iterations,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "sgd_%s_kernel" % args.mode, "kernel_avg_us": 1e3 * kernel_ms,
                          "kernel_min_us": 1e3 * kernel_ms_min, "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_update": bytes_per_update},
         }
+        traffic = measured_traffic(args.workload, f, args.mode)
+        if traffic:
+            line["roofline"]["traffic"] = traffic["bytes_per_launch"]
+            line["roofline"]["traffic_source"] = traffic["source"]
+        if ordered:
+            line["ordered_mode"] = ordered
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(train, test, f, hyper)
         print(json.dumps(line), flush=True)

@@ -378,3 +378,51 @@ def test_train_ordered_equals_serial():
         outs.append(cu.train(tr, te, cfg, mode=mode, verbose=False))
     for a, b in zip(outs[0], outs[1]):
         np.testing.assert_array_equal(a, b)
+
+
+# ------------------------------------------------------------------ multi-GPU plumbing on one GPU
+
+def test_item_exchange_kernels_and_rccl_world1():
+    """The exchange path on real hardware with world_size 1: RCCL all-reduce (backend nccl) of the fused delta
+    buffer, pack / apply kernels; ShardedSGD at N=1 must be bit-identical to the plain path (no exchange)."""
+    import torch
+    import torch.distributed as dist
+    from cu2rec_amd.engine import DeviceRatings, Engine
+    from cu2rec_amd.parallel import ShardedSGD
+    tr, te = _small_set(users=1500, items=200, nnz=30000, seed=12)
+    f = 20
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % (29500 + os.getpid() % 500), rank=0,
+                                world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eng = Engine(tr.rows, tr.cols, f, tr.global_bias)
+        ref = Engine(tr.rows, tr.cols, f, tr.global_bias)
+        d = DeviceRatings(tr, eng.device)
+        job = ShardedSGD(eng, d, sync_every=3)
+        job.run(HYPER, 42, 0, 10, "ordered")
+        ref.sgd(d, HYPER, 42, 0, 10, "ordered")
+        for a, b in zip(eng.download(), ref.download()):
+            np.testing.assert_array_equal(a, b)
+        # manual exchange: snapshot, train, pack -> all_reduce -> apply(1.0) reproduces Q up to one rounding
+        eng.snapshot_items()
+        Q0 = eng.Q.clone()
+        eng.sgd(d, HYPER, 42, 10, 5, "hogwild")
+        Q1, ib1 = eng.Q.clone(), eng.item_bias.clone()
+        buf = eng.pack_item_delta()
+        torch.testing.assert_close(buf[:Q1.numel()].view_as(Q1), Q1 - Q0, rtol=0, atol=0)
+        dist.all_reduce(buf)
+        eng.apply_item_delta(1.0)
+        torch.testing.assert_close(eng.Q, Q1, rtol=0, atol=1e-6)
+        torch.testing.assert_close(eng.item_bias, ib1, rtol=0, atol=1e-6)
+        torch.testing.assert_close(eng.Q_base, eng.Q, rtol=0, atol=0)
+        # mean merge with scale 1/2 halves the step
+        eng.sgd(d, HYPER, 42, 15, 5, "hogwild")
+        Q2 = eng.Q.clone()
+        eng.pack_item_delta()
+        eng.apply_item_delta(0.5)
+        torch.testing.assert_close(eng.Q, eng.Q_base)
+        torch.testing.assert_close(eng.Q, Q1 + 0.5 * (Q2 - Q1), rtol=0, atol=1e-6)
+        out = job.loss(DeviceRatings(te, eng.device))
+        assert out["n"] == te.nnz and np.isfinite(out["rmse"])
+    finally:
+        dist.destroy_process_group()
