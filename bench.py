@@ -164,15 +164,25 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the cu2rec_amd hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # CU2REC_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing check on a 1-GPU box); the real
+    # multi-GPU run is backend nccl (= RCCL over xGMI), one rank per GPU
+    backend = os.environ.get("CU2REC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[dev_index])
+            else:
+                dist.barrier()
 
     import cu2rec_amd as cu
     from cu2rec_amd.engine import DeviceRatings, Engine
@@ -210,7 +220,7 @@ def main():
     it += args.steps
     log("timed region: %d steps in %.4f s" % (args.steps, elapsed))
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -49,7 +49,13 @@ class ShardedSGD:
         if self.world_size == 1:
             return
         buf = self.engine.pack_item_delta()
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        if buf.is_cuda and dist.get_backend(self.group) != "nccl":
+            # debugging aid (e.g. two ranks sharing one GPU under gloo): stage through the host
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(host)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         self.engine.apply_item_delta(1.0 / self.world_size if self.merge == "mean" else 1.0)
         self.since_sync = 0
         self.exchanges += 1
