@@ -426,3 +426,44 @@ def test_item_exchange_kernels_and_rccl_world1():
         assert out["n"] == te.nnz and np.isfinite(out["rmse"])
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ next row: bin/predict
+
+def test_bin_predict_partial_fit(tmp_path):
+    """predict.cu:72-146: load Q / item_bias / global_bias written by bin/mf, fit ONE new user with the item side
+    frozen, score every item, list the unrated ones best first.  Checked against the oracle (frozen-item SGD is
+    race free, so the result is exact)."""
+    mf, predict = os.path.join(ROOT, "bin", "mf"), os.path.join(ROOT, "bin", "predict")
+    assert os.path.exists(predict), "bin/predict not built"
+    train = tmp_path / "ratings.csv"
+    train.write_text(open(os.path.join(GOLDEN, "toy_ratings.csv")).read())
+    (tmp_path / "train.cfg").write_text("0 50 4 0.05 42 0.02 0.02 0.02 0.02\n")
+    subprocess.run([mf, "-c", str(tmp_path / "train.cfg"), "-m", "ordered", str(train),
+                    os.path.join(GOLDEN, "toy_ratings2.csv")], stdout=subprocess.PIPE, check=True)
+    (tmp_path / "predict.cfg").write_text("0 200 4 0.05 42 0.02 0.02 0.02 0.02\n")
+    user_file = os.path.join(GOLDEN, "toy_user_spaces.csv")  # one user: items 1, 2, 4 rated
+    out = subprocess.run([predict, "-c", str(tmp_path / "predict.cfg"), "-i", str(tmp_path / "ratings_f4_item_bias.csv"),
+                          "-g", str(tmp_path / "ratings_f4_global_bias.csv"), "-q", str(tmp_path / "ratings_f4_q.csv"),
+                          user_file], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "Predictions: " in out and "Recommendations:" in out
+    # oracle: the same partial fit
+    Q = cu.read_array(str(tmp_path / "ratings_f4_q.csv"))
+    ib = cu.read_array(str(tmp_path / "ratings_f4_item_bias.csv")).ravel()
+    gb = float(cu.read_array(str(tmp_path / "ratings_f4_global_bias.csv")).ravel()[0])
+    u = _toy("toy_user_spaces.csv")
+    one = orc.CSR(np.array([0, u.nnz]), u.indices, u.data, 1, Q.shape[0])
+    P, ub = orc.normal_fill(4, 4).reshape(1, 4), orc.normal_fill(1, 4)
+    Qc, ibc = Q.copy(), ib.copy()
+    orc.sgd_iterations(one, P, Qc, ub, ibc, gb, (0.05, 0.02, 0.02, 0.02, 0.02), 42, 0, 200, dot_order=orc.DOT_TREE16,
+                       update_items=False)
+    np.testing.assert_array_equal(Qc, Q)
+    pred = [orc.lib().orc_predict(4, P[0].ctypes.data_as(orc.C.POINTER(orc.C.c_float)),
+                                  Q[i].ctypes.data_as(orc.C.POINTER(orc.C.c_float)), float(ub[0]), float(ib[i]), gb,
+                                  orc.DOT_SEQ) for i in range(Q.shape[0])]
+    want = sorted([(p, i) for i, p in enumerate(pred) if i not in set(u.indices.tolist())], key=lambda t: -t[0])
+    lines = [l for l in out.split("\n") if l.startswith("Rank:")]
+    assert len(lines) == len(want) == 2
+    for rank, (line, (p, i)) in enumerate(zip(lines, want)):
+        assert line == "Rank: %d\tItem: %d\tEstimated rating: %f" % (rank + 1, i, p)
+    assert subprocess.run([predict]).returncode == 2  # predict.cu:73-75
