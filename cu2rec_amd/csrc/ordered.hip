@@ -143,6 +143,125 @@ __device__ __forceinline__ void run_rows(RowTile<J, T> &tile, const SgdArgs &a, 
     }
 }
 
+// ---- hot chains, wide layout (J == 2, i.e. 65 <= ld <= 128): one float4 slot per lane over 32 lanes ----------
+// Half a wavefront owns one chain.  Per update every lane then carries 4 factors instead of 8, which halves the
+// element-wise work on the chain's critical path; the dot product keeps the canonical order (sgd_device.hpp):
+// slot partials s_0..s_31, then s_l + s_{l+16} -- here ONE v_permlane16_swap + add across the two 16-lane rows --
+// then the 16-lane butterfly, so the bits equal the 16-lane kernels'.
+constexpr int kWide = 32;
+
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float cross_row_sum(float v) {
+    // rows (r0, r1) -> both operands hold (r0 | r0) and (r1 | r1): the sum is r0 + r1 in every lane of both rows
+    const uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+__device__ __forceinline__ float4 load_wide(const float *__restrict__ base, size_t row, int ld, int nslots, int lane32) {
+    const float4 *p = reinterpret_cast<const float4 *>(base + row * static_cast<size_t>(ld));
+    const float4 v = p[min(lane32, nslots - 1)];  // branch free: out-of-row lanes re-read the last slot ...
+    const bool ok = lane32 < nslots;              // ... and drop it
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+__device__ __forceinline__ void store_wide(float *__restrict__ base, size_t row, int ld, int nslots, int lane32,
+                                           const float4 &v) {
+    float4 *p = reinterpret_cast<float4 *>(base + row * static_cast<size_t>(ld));
+    if (lane32 < nslots) p[lane32] = v;
+}
+
+// one chain update in the wide layout; same operations, same order as chain_step<2>
+__device__ __forceinline__ float chain_step_wide(const SgdArgs &a, float4 &p, float4 &q, float ub, float &ib, float rating) {
+    const float dot = row_sum16(cross_row_sum(slot_dot(q, p)));
+    const float err = rating - (((a.global_bias + ub) + ib) + dot);
+    const float4 po = p, qo = q;
+    p.x = step(po.x, qo.x, err, a.h.lr, a.h.p_reg);
+    p.y = step(po.y, qo.y, err, a.h.lr, a.h.p_reg);
+    p.z = step(po.z, qo.z, err, a.h.lr, a.h.p_reg);
+    p.w = step(po.w, qo.w, err, a.h.lr, a.h.p_reg);
+    q.x = step(qo.x, po.x, err, a.h.lr, a.h.q_reg);
+    q.y = step(qo.y, po.y, err, a.h.lr, a.h.q_reg);
+    q.z = step(qo.z, po.z, err, a.h.lr, a.h.q_reg);
+    q.w = step(qo.w, po.w, err, a.h.lr, a.h.q_reg);
+    ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
+    return ub + a.h.lr * (err - a.h.ub_reg * ub);
+}
+
+template <int T>
+struct WideTile {
+    float4 rows[T];
+};
+
+template <int T>
+__device__ __forceinline__ void load_wide_rows(WideTile<T> &tile, const SgdArgs &a, const ChunkMeta &m, int first, int lane32) {
+    const int my_user = static_cast<int>(m.val >> 32);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int x = __shfl(my_user, first + t, kWide);
+        tile.rows[t] = load_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32);
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void run_wide_rows(WideTile<T> &tile, const SgdArgs &a, const ChunkMeta &m, int first,
+                                              float4 &q, float &ib, float &my_new_ub, int lane32) {
+    const int my_user = static_cast<int>(m.val >> 32);
+    const float my_rating = __uint_as_float(static_cast<uint32_t>(m.val));
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int x = __shfl(my_user, first + t, kWide);
+        const float rating = __shfl(my_rating, first + t, kWide);
+        const float ub = __shfl(m.ub, first + t, kWide);
+        const float new_ub = chain_step_wide(a, tile.rows[t], q, ub, ib, rating);
+        store_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32, tile.rows[t]);
+        my_new_ub = lane32 == first + t ? new_ub : my_new_ub;
+    }
+}
+
+// whole chain [begin, end) of item y in the wide layout: 32-entry chunks (entries / biases fetched a chunk ahead),
+// rows fetched a tile of 8 ahead
+__device__ __forceinline__ void run_hot_chain_wide(const SgdArgs &a, const uint64_t *__restrict__ vals, int begin, int end,
+                                                   int y, int lane32) {
+    constexpr int T = 8;
+    float4 q = load_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32);
+    float ib = a.item_bias[y];
+    const int n_chunks = (end - begin) / kWide;
+    int s = begin;
+    if (n_chunks > 0) {
+        const int last_chunk = begin + (n_chunks - 1) * kWide;
+        WideTile<T> ra, rb;
+        ChunkMeta cur = load_meta(a, vals, s, lane32);
+        load_wide_rows<T>(ra, a, cur, 0, lane32);
+        for (int c = 0; c < n_chunks; ++c) {
+            const ChunkMeta nxt = load_meta(a, vals, min(s + kWide, last_chunk), lane32);
+            float my_new_ub = 0.f;
+            load_wide_rows<T>(rb, a, cur, 8, lane32);
+            run_wide_rows<T>(ra, a, cur, 0, q, ib, my_new_ub, lane32);
+            load_wide_rows<T>(ra, a, cur, 16, lane32);
+            run_wide_rows<T>(rb, a, cur, 8, q, ib, my_new_ub, lane32);
+            load_wide_rows<T>(rb, a, cur, 24, lane32);
+            run_wide_rows<T>(ra, a, cur, 16, q, ib, my_new_ub, lane32);
+            load_wide_rows<T>(ra, a, nxt, 0, lane32);  // last chunk: a discarded re-load
+            run_wide_rows<T>(rb, a, cur, 24, q, ib, my_new_ub, lane32);
+            a.user_bias[static_cast<int>(cur.val >> 32)] = my_new_ub;  // 32 users, one store
+            cur = nxt;
+            s += kWide;
+        }
+    }
+    for (; s < end; ++s) {  // fewer than 32 entries left
+        const uint64_t val = vals[s];
+        const int x = static_cast<int>(val >> 32);
+        float4 p = load_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32);
+        const float ub = a.user_bias[x];
+        const float new_ub = chain_step_wide(a, p, q, ub, ib, __uint_as_float(static_cast<uint32_t>(val)));
+        store_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32, p);
+        if (lane32 == 0) a.user_bias[x] = new_ub;
+    }
+    store_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32, q);
+    if (lane32 == 0) a.item_bias[y] = ib;
+}
+
 // first position in keys[0, n) whose key is >= target
 __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys, int n, uint32_t target) {
     int lo = 0, hi = n;
@@ -172,6 +291,15 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
                                                              int hot_blocks) {
     const int lane = threadIdx.x & (kGroup - 1);
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
+        if constexpr (J == 2) {
+            // wide layout: half a wavefront per chain
+            const int r = (blockIdx.x * kBlock + threadIdx.x) / kWide;
+            if (r >= n_hot) return;
+            const int begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
+            const int end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));
+            if (begin < end) run_hot_chain_wide(a, vals, begin, end, item_of_rank[r], threadIdx.x & (kWide - 1));
+            return;
+        }
         constexpr int T = HotTile<J>::value;
         const int r = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
         if (r >= n_hot) return;
@@ -264,7 +392,8 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream) {
-    const int hot_blocks = (n_hot + kGroupsPerBlock - 1) / kGroupsPerBlock;
+    const int chains_per_block = J == 2 ? kBlock / kWide : kGroupsPerBlock;  // J == 2 uses the wide layout
+    const int hot_blocks = (n_hot + chains_per_block - 1) / chains_per_block;
     const int groups = (n_active + kWindow - 1) / kWindow;
     const int blocks = hot_blocks + (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
     hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,

@@ -60,18 +60,27 @@ __device__ __forceinline__ void store_row(float *__restrict__ base, size_t row, 
     }
 }
 
-// util.cu:199-204 get_prediction, in the group's order: per-lane fmaf chain in slot order,
-// butterfly, then ((gb + ub) + ib) + dot.
+// One float4 slot's share of the dot product: a 4-term fmaf chain starting from +0.
+__device__ __forceinline__ float slot_dot(const float4 &q, const float4 &p) {
+    float s = __builtin_fmaf(q.x, p.x, 0.f);
+    s = __builtin_fmaf(q.y, p.y, s);
+    s = __builtin_fmaf(q.z, p.z, s);
+    s = __builtin_fmaf(q.w, p.w, s);
+    return s;
+}
+
+// util.cu:199-204 get_prediction in the kernels' canonical order ("TREE16" in the oracle):
+//   slot partial  s_k   = fmaf chain over the 4 floats of slot k
+//   lane total    t_l   = ((s_l + s_{l+16}) + s_{l+32}) + ...        (l = 0..15)
+//   dot                 = xor butterfly 1, 2, 4, 8 over t_0..t_15
+//   prediction          = ((gb + ub) + ib) + dot
+// Slot partials are independent, so a layout with one slot per lane over 32 lanes (ordered.hip, hot chains)
+// produces the same bits: s_l + s_{l+16} is then one cross-row add.
 template <int J>
 __device__ __forceinline__ float predict(const Row<J> &p, const Row<J> &q, float ub, float ib, float gb) {
-    float acc = 0.f;
+    float acc = slot_dot(q.v[0], p.v[0]);
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        acc = __builtin_fmaf(q.v[j].x, p.v[j].x, acc);
-        acc = __builtin_fmaf(q.v[j].y, p.v[j].y, acc);
-        acc = __builtin_fmaf(q.v[j].z, p.v[j].z, acc);
-        acc = __builtin_fmaf(q.v[j].w, p.v[j].w, acc);
-    }
+    for (int j = 1; j < J; ++j) acc = acc + slot_dot(q.v[j], p.v[j]);
     const float dot = row_sum16(acc);
     return ((gb + ub) + ib) + dot;
 }

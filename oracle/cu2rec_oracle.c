@@ -230,14 +230,19 @@ int orc_sample(uint64_t seed, uint64_t user, uint64_t iteration, int low, int hi
 static float dot_tree16(int f, const float *p, const float *q) {
     float lane[16];
     const int nslots = (f + 3) / 4;
+    const int per_lane = (nslots + 15) / 16; /* slots per lane in the kernels' layout (zero padded) */
     for (int l = 0; l < 16; ++l) {
+        /* lane total: slot partials (4-term fmaf chains from +0) added in slot order */
         float acc = 0.0f;
-        for (int s = l; s < nslots; s += 16) {
+        for (int j = 0; j < (per_lane > 0 ? per_lane : 1); ++j) {
+            const int s = l + 16 * j;
+            float part = 0.0f;
             for (int c = 0; c < 4; ++c) {
-                int e = 4 * s + c;
-                float qv = e < f ? q[e] : 0.0f, pv = e < f ? p[e] : 0.0f;
-                acc = fmaf(qv, pv, acc);
+                const int e = 4 * s + c;
+                const float qv = e < f ? q[e] : 0.0f, pv = e < f ? p[e] : 0.0f;
+                part = fmaf(qv, pv, part);
             }
+            acc = j == 0 ? part : acc + part;
         }
         lane[l] = acc;
     }
