@@ -25,6 +25,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -452,7 +453,9 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
     if (n_active == 0) return;
     const uint32_t item_mask = (1u << item_bits) - 1u;
     // ranks [0, n_hot) get a dedicated group each with deep prefetch; keep r + 1 representable in item_bits
-    const int n_hot = std::min(std::min(n_cols, kHotChains), static_cast<int>(item_mask));
+    int hot_wanted = kHotChains;
+    if (const char *env = std::getenv("CU2REC_ORDERED_HOT")) hot_wanted = std::max(0, std::atoi(env));  // tuning aid
+    const int n_hot = std::min(std::min(n_cols, hot_wanted), static_cast<int>(item_mask));
     int done = 0;
     while (done < n_iters) {
         const int nb = std::min(max_batch, n_iters - done);
