@@ -85,3 +85,78 @@ class ShardedSGD:
             t = t.cpu()
         sa, ss, n = (float(v) for v in t)
         return {"mae": sa / n, "rmse": (ss / n) ** 0.5, "sum_abs": sa, "sum_sq": ss, "n": n}
+
+
+def train_sharded(train, test, cfg, mode=api.SGD_HOGWILD, sync_every=0, merge="mean", verbose=True, device=None,
+                  engine_factory=None):
+    """train() (training.h:14-15) over all ranks of the default process group: the same observable schedule as
+    cu2rec_train -- loss on train and test at i == 0, every check_error and last (training.cu:118), the TRAIN:/TEST:
+    lines (rank 0), patience / learning-rate decay on the GLOBAL test RMSE (training.cu:146-155; identical on every
+    rank because the loss sums are all-reduced), cfg.learning_rate / cfg.cur_iterations updated in place.
+
+    train / test: the FULL HostCSR on every rank (each rank slices its own contiguous user range).
+    Returns (P_local, Q, losses, user_bias_local, item_bias, (u0, u1)): the rank's user slice plus the merged item
+    side.  sync_every == 0 means one epoch = nnz / users iterations."""
+    import time
+
+    import numpy as np
+
+    rank, world_size = world()
+    bounds = plan_users(train.rows, world_size)
+    u0, u1 = bounds[rank], bounds[rank + 1]
+    if test.rows < train.rows:  # a test file may name fewer users than train (mf.cu:50-51): pad with empty rows
+        test = api.HostCSR(np.concatenate([test.indptr, np.full(train.rows - test.rows, test.nnz, np.int32)]),
+                           test.indices, test.data, train.rows, train.cols, test.global_bias)
+    tr, te = train.slice_users(u0, u1), test.slice_users(u0, u1)
+    f = cfg.n_factors
+    # every rank draws the reference's seed-42 initialisation and keeps its slice, so N ranks start exactly where
+    # one rank would (training.cu:28,54,212-213)
+    P0 = api.initialize_normal_array(train.rows * f, f).reshape(train.rows, f)[u0:u1]
+    ub0 = api.initialize_normal_array(train.rows, f)[u0:u1]
+    if engine_factory is None:
+        from .engine import DeviceRatings, Engine
+        eng = Engine(u1 - u0, train.cols, f, train.global_bias, P=P0, user_bias=ub0, device=device)
+        d_tr, d_te = DeviceRatings(tr, eng.device), DeviceRatings(te, eng.device)
+    else:
+        eng, d_tr, d_te = engine_factory(u1 - u0, train.cols, f, train.global_bias, P0, ub0, tr, te)
+    users_active = float(np.count_nonzero(np.diff(train.indptr)))
+    every = sync_every or max(1, int(round(train.nnz / max(users_active, 1.0))))
+    job = ShardedSGD(eng, d_tr, user_offset=u0, sync_every=every, merge=merge)
+
+    total = cfg.total_iterations
+    losses = np.full(max(total, 1), np.nan, np.float32)
+    validation_rmse = float(np.finfo(np.float32).max)
+    patience = int(cfg.patience)
+    iter_base, seed = int(cfg.cur_iterations), int(cfg.seed) & 0xFFFFFFFF
+    t_start = time.perf_counter()
+    i = 0
+    while i < total:
+        seg_end = i
+        while not ((seg_end + 1) % cfg.check_error == 0 or seg_end == 0 or (seg_end + 1) % total == 0):
+            seg_end += 1
+        n = seg_end - i + 1
+        hyper = (cfg.learning_rate, cfg.P_reg, cfg.Q_reg, cfg.user_bias_reg, cfg.item_bias_reg)
+        job.run(hyper, seed, iter_base + i, n, mode, bool(cfg.is_train))
+        if world_size > 1 and cfg.is_train and job.since_sync:
+            job.exchange()  # the loss below is taken on reconciled item factors
+        tr_loss = job.loss(d_tr)
+        last = validation_rmse
+        te_loss = job.loss(d_te)
+        validation_rmse = float(np.float32(te_loss["rmse"]))
+        if verbose and rank == 0:
+            print("TRAIN: Iteration %d GPU MAE: %f RMSE: %f" % (seg_end + 1, tr_loss["mae"], tr_loss["rmse"]))
+            print("TEST: Iteration %d GPU MAE: %f RMSE: %f" % (seg_end + 1, te_loss["mae"], te_loss["rmse"]), flush=True)
+        if last < validation_rmse:
+            patience -= 1
+        if patience <= 0:
+            patience = int(cfg.patience)
+            cfg.learning_rate = float(np.float32(cfg.learning_rate) * np.float32(cfg.learning_rate_decay))
+            if verbose and rank == 0:
+                print("New Learning Rate: %f\n: " % cfg.learning_rate, end="")
+        losses[seg_end] = validation_rmse
+        cfg.cur_iterations += n
+        i = seg_end + 1
+    if verbose and rank == 0:
+        print("Time taken for %d of iterations is %f" % (total, time.perf_counter() - t_start))
+    P, Q, ub, ib = eng.download()
+    return P, Q, losses[:total], ub, ib, (u0, u1)

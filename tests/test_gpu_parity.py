@@ -467,3 +467,35 @@ def test_bin_predict_partial_fit(tmp_path):
     for rank, (line, (p, i)) in enumerate(zip(lines, want)):
         assert line == "Rank: %d\tItem: %d\tEstimated rating: %f" % (rank + 1, i, p)
     assert subprocess.run([predict]).returncode == 2  # predict.cu:73-75
+
+
+def test_train_sharded_world1_equals_cpp_train(tmp_path):
+    """The multi-GPU train driver at N=1 (real HIP engine) is bit-identical to cu2rec_train, and the multi-GPU CLI
+    module writes the same five files as bin/mf."""
+    from cu2rec_amd.parallel import train_sharded
+    tr, te = _small_set(seed=7)
+    kw = dict(total_iterations=24, n_factors=12, check_error=6, learning_rate=0.03, patience=1.0)
+    cfg_a, cfg_b = cu.default_config(**kw), cu.default_config(**kw)
+    a = cu.train(tr, te, cfg_a, mode="ordered", verbose=False)
+    b = train_sharded(tr, te, cfg_b, mode="ordered", verbose=False)
+    for x, y in zip(a, b[:5]):
+        np.testing.assert_array_equal(x, y)
+    assert cfg_a.learning_rate == cfg_b.learning_rate and cfg_a.cur_iterations == cfg_b.cur_iterations == 24
+    # CLI: python -m cu2rec_amd.mf_mgpu (one process) vs bin/mf
+    from cu2rec_amd import synth as _synth
+    d1, d2 = tmp_path / "a", tmp_path / "b"
+    d1.mkdir(), d2.mkdir()
+    for d in (d1, d2):
+        _synth.write_csv(str(d / "train.csv"), tr)
+        _synth.write_csv(str(d / "test.csv"), te)
+        (d / "c.cfg").write_text("0 24 12 0.03 42 0.02 0.02 0.02 0.02\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    subprocess.run([os.path.join(ROOT, "bin", "mf"), "-c", str(d1 / "c.cfg"), "-m", "ordered", str(d1 / "train.csv"),
+                    str(d1 / "test.csv")], stdout=subprocess.PIPE, check=True)
+    import sys
+    out = subprocess.run([sys.executable, "-m", "cu2rec_amd.mf_mgpu", "-c", str(d2 / "c.cfg"), "-m", "ordered",
+                          str(d2 / "train.csv"), str(d2 / "test.csv")], stdout=subprocess.PIPE, text=True, check=True,
+                         env=env, cwd=ROOT).stdout
+    assert "TEST: Iteration 24 GPU MAE:" in out
+    for comp in ("p", "q", "user_bias", "item_bias", "global_bias"):
+        assert (d1 / ("train_f12_%s.csv" % comp)).read_text() == (d2 / ("train_f12_%s.csv" % comp)).read_text(), comp

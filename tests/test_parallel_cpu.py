@@ -71,6 +71,9 @@ class OracleEngine:
         o = orc.CSR(ratings.indptr, ratings.indices, ratings.data, ratings.rows, ratings.cols)
         return orc.loss(o, self.P, self.Q, self.ub, self.ib, self.global_bias)
 
+    def download(self):
+        return self.P.copy(), self.Q.copy(), self.ub.copy(), self.ib.copy()
+
 
 def test_single_rank_cadence_terminates_and_matches_oracle():
     tr, te = synth.make_ratings(60, 30, 600, min_degree=2, seed=2)
@@ -137,3 +140,57 @@ def test_two_ranks_gloo(tmp_path):
         np.testing.assert_allclose(r[k]["ib"], engs[k].ib, atol=1e-6)
     # after the last exchange both replicas agreed; they then drifted for 2 local iterations
     assert float(r[0]["rmse"]) == float(r[1]["rmse"]) and int(r[0]["n"]) == te.nnz  # global loss is all-reduced
+
+
+def _oracle_factory(rows, cols, f, gb, P0, ub0, tr, te):
+    Q = orc.normal_fill(cols * f, f).reshape(cols, f)
+    ib = orc.normal_fill(cols, f)
+    return OracleEngine(rows, cols, f, gb, P0, Q, ub0, ib), tr, te
+
+
+def test_train_sharded_single_rank_matches_oracle_train(capsys):
+    """train_sharded with one rank: the training.cu schedule (cadence, patience / LR decay, printed lines)."""
+    from cu2rec_amd.parallel import train_sharded
+    tr, te = synth.make_ratings(60, 30, 700, min_degree=2, seed=4)
+    cfg = cu.default_config(total_iterations=20, n_factors=6, check_error=5, learning_rate=0.05, patience=1.0)
+    ocfg = orc.default_config(total_iterations=20, n_factors=6, check_error=5, learning_rate=0.05, patience=1.0)
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, 6)
+    log = orc.train(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols), orc.CSR(te.indptr, te.indices, te.data, te.rows, te.cols),
+                    ocfg, P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_SEQ, acc=orc.ACC_F64, schedule=orc.SCHED_PATIENCE)
+    gP, gQ, losses, gub, gib, (u0, u1) = train_sharded(tr, te, cfg, engine_factory=_oracle_factory, verbose=True)
+    assert (u0, u1) == (0, tr.rows)
+    np.testing.assert_allclose(gP, P, atol=1e-6)
+    np.testing.assert_allclose(gQ, Q, atol=1e-6)
+    assert [e["iteration"] - 1 for e in log] == [i for i in range(20) if not np.isnan(losses[i])] == [0, 4, 9, 14, 19]
+    for e in log:
+        assert abs(losses[e["iteration"] - 1] - e["test_rmse"]) < 1e-6
+    assert abs(cfg.learning_rate - ocfg.learning_rate) < 1e-9 and cfg.cur_iterations == 20
+    out = capsys.readouterr().out
+    assert "TRAIN: Iteration 1 GPU MAE:" in out and "TEST: Iteration 20 GPU MAE:" in out and "Time taken for 20 of iterations" in out
+
+
+def _train_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cu2rec_amd.parallel import train_sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr, te = synth.make_ratings(90, 25, 1000, min_degree=2, seed=6)
+    cfg = cu.default_config(total_iterations=12, n_factors=5, check_error=4, learning_rate=0.02)
+    P, Q, losses, ub, ib, (u0, u1) = train_sharded(tr, te, cfg, sync_every=3, engine_factory=_oracle_factory, verbose=False)
+    np.savez(os.path.join(out_dir, "t%d.npz" % rank), Q=Q, ib=ib, losses=losses, u0=u0, u1=u1, lr=cfg.learning_rate)
+    dist.destroy_process_group()
+
+
+def test_train_sharded_two_ranks_gloo(tmp_path):
+    world, port = 2, 31000 + os.getpid() % 2000
+    mp.spawn(_train_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (np.load(str(tmp_path / ("t%d.npz" % k))) for k in range(2))
+    assert (int(a["u0"]), int(a["u1"]), int(b["u0"]), int(b["u1"])) == (0, 45, 45, 90)
+    # after the final exchange both ranks hold the same item side and saw the same global losses / LR
+    np.testing.assert_array_equal(a["Q"], b["Q"])
+    np.testing.assert_array_equal(a["ib"], b["ib"])
+    np.testing.assert_array_equal(np.nan_to_num(a["losses"]), np.nan_to_num(b["losses"]))
+    assert float(a["lr"]) == float(b["lr"])
+    checked = [i for i in range(12) if not np.isnan(a["losses"][i])]
+    assert checked == [0, 3, 7, 11] and a["losses"][11] < a["losses"][0]
