@@ -77,3 +77,57 @@ def test_stream_equals_rocrand(tmp_path):
         x, u = line.split()
         assert int(x) == orc.lib().orc_draw(seed, user, it)
         assert np.float32(float(u)) == np.float32(orc.lib().orc_uniform(int(x)))
+
+
+ROCRAND_DEVICE_SRC = r"""
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+__global__ void draw(const unsigned long long* in, unsigned int* out_x, float* out_u, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(in[3 * i], in[3 * i + 1], 4ULL * in[3 * i + 2], &st);   // device API, on the GPU
+    rocrand_state_philox4x32_10 st2 = st;
+    out_x[i] = rocrand(&st);
+    out_u[i] = rocrand_uniform(&st2);
+}
+int main(int argc, char** argv) {
+    int n = (argc - 1) / 3;
+    std::vector<unsigned long long> h(3 * n);
+    for (int i = 0; i < 3 * n; ++i) h[i] = strtoull(argv[1 + i], 0, 10);
+    unsigned long long* d_in; unsigned int* d_x; float* d_u;
+    if (hipMalloc(&d_in, h.size() * 8) != hipSuccess) return 2;
+    hipMalloc(&d_x, n * 4); hipMalloc(&d_u, n * 4);
+    hipMemcpy(d_in, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    draw<<<(n + 63) / 64, 64>>>(d_in, d_x, d_u, n);
+    std::vector<unsigned int> x(n); std::vector<float> u(n);
+    if (hipMemcpy(x.data(), d_x, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+    hipMemcpy(u.data(), d_u, n * 4, hipMemcpyDeviceToHost);
+    for (int i = 0; i < n; ++i) printf("%u %.9g\n", x[i], u[i]);
+    return 0;
+}
+"""
+
+
+@pytest.mark.gpu
+def test_stream_equals_rocrand_device_api(tmp_path):
+    """The sampler the kernels compute in registers is rocRAND's Philox4x32-10 device stream (north star: cuRAND ->
+    rocRAND): a kernel that calls rocrand_init / rocrand / rocrand_uniform on the GPU draws the same words."""
+    import cu2rec_amd as cu
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = tmp_path / "rrd.hip"
+    src.write_text(ROCRAND_DEVICE_SRC)
+    exe = tmp_path / "rrd"
+    subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-w", "-o", str(exe), str(src)], check=True)
+    rng = np.random.RandomState(11)
+    triples = [(42, 0, 0), (42, 138492, 9999), (7, 1, 2**33)]
+    triples += [(int(rng.randint(0, 2**31)), int(rng.randint(0, 2**31)), int(rng.randint(0, 2**31))) for _ in range(200)]
+    out = subprocess.run([str(exe)] + [str(v) for t in triples for v in t], check=True, stdout=subprocess.PIPE,
+                         text=True).stdout.split("\n")
+    for (seed, user, it), line in zip(triples, out):
+        x, u = line.split()
+        assert int(x) == cu.lib().cu2rec_sampler_draw(seed, user, it) == orc.lib().orc_draw(seed, user, it)
+        assert np.float32(float(u)) == np.float32(orc.lib().orc_uniform(int(x)))
