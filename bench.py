@@ -148,6 +148,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20240917)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-samples", type=int, default=200)
+    ap.add_argument("--iters-per-launch", type=int, default=1,
+                    help="Hogwild launch blocking (opt-in, not the reference cadence): updates per user per launch")
     ap.add_argument("--ordered-steps", type=int, default=128,
                     help="extra (untimed for `value`) pass in the exact ordered mode, reported beside the headline; 0 = skip")
     args = ap.parse_args()
@@ -200,6 +202,8 @@ def main():
     d_train, d_test = DeviceRatings(train, device), DeviceRatings(test, device)
     # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the global population
     job = ShardedSGD(eng, d_train, user_offset=rank * train.rows, sync_every=sync_every, merge=args.merge)
+    if args.iters_per_launch > 1:
+        cu.lib().cu2rec_hogwild_iters_per_launch(args.iters_per_launch)
     mode = {"hogwild": cu.SGD_HOGWILD, "serial": cu.SGD_SERIAL, "ordered": cu.SGD_ORDERED}[args.mode]
     log("model + ratings resident in HBM")
     rmse0 = job.loss(d_test)["rmse"]
@@ -227,11 +231,12 @@ def main():
     # ---- SGD kernel duration: HIP events around single launches on the launch stream (untimed extra pass)
     n_s = max(args.kernel_samples, 1)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_s)]
+    k_launch = max(args.iters_per_launch, 1) if args.mode == "hogwild" else 1  # iterations covered by one launch
     for a, b in evs:
         a.record()
-        eng.sgd(d_train, hyper, 42, it, 1, mode, True, rank * train.rows)
+        eng.sgd(d_train, hyper, 42, it, k_launch, mode, True, rank * train.rows)
         b.record()
-        it += 1
+        it += k_launch
     torch.cuda.synchronize()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     kernel_ms_min = float(np.min([a.elapsed_time(b) for a, b in evs]))
@@ -257,7 +262,7 @@ def main():
         log("ordered mode: %.3f ms/step" % ordered["ms_per_step"])
         del eng_o
     bytes_per_update = 16 * f + 32
-    alg_bytes = users_active * bytes_per_update
+    alg_bytes = users_active * bytes_per_update * k_launch
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     value = world * users_active * args.steps / elapsed
 
@@ -267,8 +272,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s-shape synthetic ratings (users %d, items %d, train nnz %d, test nnz %d per GPU), "
-                                   "f=%d, lr .01, reg .02, mode %s" % (args.workload, train.rows, train.cols, train.nnz,
-                                                                         test.nnz, f, args.mode),
+                                   "f=%d, lr .01, reg .02, mode %s%s" % (args.workload, train.rows, train.cols, train.nnz, test.nnz, f,
+                                                                           args.mode, "" if args.iters_per_launch == 1 else
+                                                                           " x%d iterations per launch" % args.iters_per_launch),
                        "updates_per_step_per_gpu": users_active, "sync_every": sync_every if world > 1 else None,
                        "merge": args.merge if world > 1 else None, "exchanges": job.exchanges},
             "test_rmse": final["rmse"], "test_rmse_initial": rmse0, "iterations_run": final_iterations,

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcu2rec_amd.so")
+# CU2REC_AMD_LIB: load another build of the same library (ablation / tuning builds)
+LIB_PATH = os.environ.get("CU2REC_AMD_LIB") or os.path.join(HERE, "libcu2rec_amd.so")
 
 
 class Cu2recError(RuntimeError):
@@ -71,6 +72,7 @@ SIGNATURES = {
     "cu2rec_sampler_index": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
     "cu2rec_sgd_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,
                                     C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "cu2rec_hogwild_iters_per_launch": (C.c_int, [C.c_int]),
     "cu2rec_schedule_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "cu2rec_schedule_destroy": (None, [_P]),
     "cu2rec_sgd_update_ordered": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,

@@ -1,6 +1,8 @@
 // Device side of the C ABI: raw-pointer hot-path entry points, owned device objects
 // (the roles of CudaCSRMatrix / CudaDenseMatrix, matrix.h:11-28) and the item-factor exchange
 // helpers.  Host code calls HIP directly; there is no CPU fallback anywhere in this file.
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -14,6 +16,8 @@ namespace cu2rec {
 namespace {
 
 hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
+
+std::atomic<int> g_hogwild_block{1};  // updates per user per Hogwild launch (cu2rec_hogwild_iters_per_launch)
 
 void check_ld(int ld, int n_factors, const char *what) {
     if (ld < n_factors || (ld & 3) != 0)
@@ -96,9 +100,10 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
     } else {
         // one launch per reference iteration (training.cu:107-113): the kernel boundary is the
         // point where every user's update of iteration i is visible to iteration i+1
-        a.iters = 1;
-        for (int i = 0; i < n_iters; ++i) {
+        const int block = std::max(1, g_hogwild_block.load());
+        for (int i = 0; i < n_iters; i += block) {
             a.iter0 = iter0 + static_cast<uint64_t>(i);
+            a.iters = std::min(block, n_iters - i);
             launch_sgd(a, mode, stream);
         }
     }
@@ -337,6 +342,12 @@ int cu2rec_sgd_update(const int *indptr, const int *indices, const float *data, 
         sgd_update(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,
                    *hyper, seed, iter0, n_iters, mode, update_items, user_offset, as_stream(stream));
     });
+}
+
+int cu2rec_hogwild_iters_per_launch(int k) {
+    const int prev = g_hogwild_block.load();
+    if (k >= 1) g_hogwild_block.store(k);
+    return prev;
 }
 
 int cu2rec_schedule_create(const int *indptr, const int *indices, int n_rows, int n_cols, int nnz,

@@ -149,6 +149,9 @@ __device__ __forceinline__ void run_rows(RowTile<J, T> &tile, const SgdArgs &a, 
 // element-wise work on the chain's critical path; the dot product keeps the canonical order (sgd_device.hpp):
 // slot partials s_0..s_31, then s_l + s_{l+16} -- here ONE v_permlane16_swap + add across the two 16-lane rows --
 // then the 16-lane butterfly, so the bits equal the 16-lane kernels'.
+#ifndef CU2REC_ABLATE
+#define CU2REC_ABLATE 0
+#endif
 constexpr int kWide = 32;
 
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
@@ -199,8 +202,12 @@ __device__ __forceinline__ void load_wide_rows(WideTile<T> &tile, const SgdArgs 
     const int my_user = static_cast<int>(m.val >> 32);
 #pragma unroll
     for (int t = 0; t < T; ++t) {
+#if CU2REC_ABLATE & 4
+        tile.rows[t] = make_float4(0.01f * t, 0.02f, 0.03f, 0.04f);  // timing only: no row loads
+#else
         const int x = __shfl(my_user, first + t, kWide);
         tile.rows[t] = load_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32);
+#endif
     }
 }
 
@@ -211,11 +218,19 @@ __device__ __forceinline__ void run_wide_rows(WideTile<T> &tile, const SgdArgs &
     const float my_rating = __uint_as_float(static_cast<uint32_t>(m.val));
 #pragma unroll
     for (int t = 0; t < T; ++t) {
+#if CU2REC_ABLATE & 2
+        const int x = my_user + t;  // timing only: no cross-lane traffic
+        const float rating = my_rating;
+        const float ub = m.ub;
+#else
         const int x = __shfl(my_user, first + t, kWide);
         const float rating = __shfl(my_rating, first + t, kWide);
         const float ub = __shfl(m.ub, first + t, kWide);
+#endif
         const float new_ub = chain_step_wide(a, tile.rows[t], q, ub, ib, rating);
+#if !(CU2REC_ABLATE & 1)
         store_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32, tile.rows[t]);
+#endif
         my_new_ub = lane32 == first + t ? new_ub : my_new_ub;
     }
 }

@@ -158,6 +158,13 @@ int cu2rec_sgd_update(const int *indptr, const int *indices, const float *data, 
                       int n_factors, const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters,
                       int mode, int update_items, int user_offset, void *stream);
 
+/* Hogwild launch blocking (process-wide, default 1 = the reference's cadence: one launch per iteration, every user's
+ * update of iteration i visible before iteration i+1 starts, training.cu:107-113).  With k > 1 a launch performs k
+ * consecutive updates per user with the user's row held in registers (P traffic / k); users are then up to k-1
+ * iterations apart inside a launch -- still Hogwild, but not the reference's interleaving, so it is opt-in.
+ * Returns the previous value; k < 1 only queries. */
+int cu2rec_hogwild_iters_per_launch(int k);
+
 /* Workspace of CU2REC_SGD_ORDERED for one device CSR: item popularity ranks, key/value buffers of the
  * per-iteration schedule, sort scratch.  indptr / indices are device pointers (read once at creation). */
 typedef struct cu2rec_schedule cu2rec_schedule;

@@ -172,6 +172,24 @@ def test_sgd_hogwild_exact_when_no_item_is_shared():
         np.testing.assert_array_equal(g, w)
 
 
+def test_sgd_hogwild_blocked_launches():
+    """Opt-in launch blocking (k updates per user per launch, user row in registers): with no shared items it is
+    still the sequential result bit for bit, including a remainder block; the knob restores to 1."""
+    n, f = 3000, 50
+    rng = np.random.RandomState(1)
+    m = cu.HostCSR(np.arange(n + 1), rng.permutation(n), rng.randint(1, 6, n).astype(np.float32), n, n, 3.0)
+    P, Q, ub, ib = orc.init_model(n, n, f)
+    model = cu.Model(n, n, f, 3.0)
+    assert cu.lib().cu2rec_hogwild_iters_per_launch(4) == 1
+    try:
+        model.sgd(cu.DeviceCSR(m), HYPER, 42, 0, 10, mode="hogwild")  # blocks of 4, 4, 2
+    finally:
+        assert cu.lib().cu2rec_hogwild_iters_per_launch(1) == 4
+    orc.sgd_iterations(_as_orc(m), P, Q, ub, ib, 3.0, HYPER, 42, 0, 10, dot_order=orc.DOT_TREE16)
+    for g, w in zip(model.download(), (P, Q, ub, ib)):
+        np.testing.assert_array_equal(g, w)
+
+
 @pytest.mark.parametrize("f", [10, 100])
 def test_sgd_hogwild_one_iteration_is_jacobi(f):
     """One Hogwild iteration: every user's P row / bias is the update computed from the item row as it
