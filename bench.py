@@ -261,6 +261,25 @@ def main():
                    "test_rmse": eng_o.loss(d_test)["rmse"], "iterations_run": 64 + args.ordered_steps}
         log("ordered mode: %.3f ms/step" % ordered["ms_per_step"])
         del eng_o
+    # ---- opt-in Hogwild launch blocking beside it (4 updates per user per launch, user row in registers)
+    blocked = None
+    if world == 1 and args.mode == "hogwild" and args.iters_per_launch == 1 and args.ordered_steps > 0:
+        eng_b = Engine(train.rows, train.cols, f, train.global_bias, device=device)
+        cu.lib().cu2rec_hogwild_iters_per_launch(4)
+        try:
+            eng_b.sgd(d_train, hyper, 42, 0, 100, cu.SGD_HOGWILD)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng_b.sgd(d_train, hyper, 42, 100, 2000, cu.SGD_HOGWILD)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+        finally:
+            cu.lib().cu2rec_hogwild_iters_per_launch(1)
+        blocked = {"mode": "hogwild, 4 iterations per launch (opt-in: users up to 3 iterations apart inside a launch)",
+                   "value": users_active * 2000 / dt, "unit": "updates/s", "ms_per_step": 1e3 * dt / 2000, "steps": 2000,
+                   "test_rmse": eng_b.loss(d_test)["rmse"], "iterations_run": 2100}
+        log("hogwild x4 per launch: %.4f ms/step" % blocked["ms_per_step"])
+        del eng_b
     bytes_per_update = 16 * f + 32
     alg_bytes = users_active * bytes_per_update * k_launch
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -290,6 +309,8 @@ def main():
             line["roofline"]["traffic_source"] = traffic["source"]
         if ordered:
             line["ordered_mode"] = ordered
+        if blocked:
+            line["hogwild_blocked_mode"] = blocked
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(train, test, f, hyper)
         print(json.dumps(line), flush=True)

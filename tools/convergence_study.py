@@ -34,6 +34,10 @@ def main():
     d_tr, d_te = cu.DeviceCSR(train), cu.DeviceCSR(test)
     out = {"workload": args.workload, "f": f, "hyper": hyper, "iters": args.iters, "curves": {}}
     for mode in args.modes.split(","):
+        block = 1
+        if ":" in mode:  # e.g. hogwild:4 = Hogwild with 4 iterations per launch
+            mode, block = mode.split(":")[0], int(mode.split(":")[1])
+        cu.lib().cu2rec_hogwild_iters_per_launch(block)
         model = cu.Model(train.rows, train.cols, f, train.global_bias)
         curve, t_sgd = [(0, model.loss(d_te)["rmse"], model.loss(d_tr)["rmse"])], 0.0
         for it in range(0, args.iters, args.every):
@@ -42,6 +46,8 @@ def main():
             r = model.loss(d_te)
             t_sgd += time.perf_counter() - t0
             curve.append((it + args.every, r["rmse"], model.loss(d_tr)["rmse"]))
+        cu.lib().cu2rec_hogwild_iters_per_launch(1)
+        mode = mode if block == 1 else "%s_x%d" % (mode, block)
         out["curves"][mode] = {"points": curve, "seconds": t_sgd}
         print(mode, "%.2fs" % t_sgd, " ".join("%d:%.5f" % (a, b) for a, b, _ in curve), flush=True)
     if not args.no_oracle:
