@@ -59,6 +59,8 @@ SIGNATURES = {
     "cu2rec_config_write": (C.c_int, [C.c_char_p, C.POINTER(Config)]),
     "cu2rec_config_print": (C.c_int, [C.POINTER(Config)]),
     "cu2rec_ratings_read_csv": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "cu2rec_ratings_save_binary": (C.c_int, [_P, C.c_char_p]),
+    "cu2rec_ratings_load_binary": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "cu2rec_ratings_info": (C.c_int, [_P, _ip, _ip, _ip, _fp]),
     "cu2rec_ratings_view": (C.c_int, [_P, C.POINTER(_ip), C.POINTER(_ip), C.POINTER(_fp)]),
     "cu2rec_ratings_free": (None, [_P]),

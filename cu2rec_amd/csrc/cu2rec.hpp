@@ -2,6 +2,9 @@
 // exception, i.e. the error behaviour of the reference's CHECK_CUDA (util.h:27-34).
 #pragma once
 
+#include <sys/stat.h>
+
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -21,9 +24,22 @@ struct HostCsr {  // createSparseMatrix's host arrays (util.cu:152-166)
     float global_bias = 0.f;
 };
 
-inline HostCsr load_ratings(const std::string &path) {  // readCSV + createSparseMatrix, mf.cu:43-44
+// readCSV + createSparseMatrix, mf.cu:43-44.  With CU2REC_RATINGS_CACHE=1 in the environment a binary copy
+// "<path>.cu2rec" is written after the first parse and loaded instead of the text while it is newer than it.
+inline HostCsr load_ratings(const std::string &path) {
     cu2rec_ratings *r = nullptr;
-    check(cu2rec_ratings_read_csv(path.c_str(), &r));
+    const char *want_cache = std::getenv("CU2REC_RATINGS_CACHE");
+    const std::string cache = path + ".cu2rec";
+    bool from_cache = false;
+    if (want_cache && *want_cache == '1') {
+        struct stat text_st, cache_st;
+        if (stat(path.c_str(), &text_st) == 0 && stat(cache.c_str(), &cache_st) == 0 && cache_st.st_mtime >= text_st.st_mtime)
+            from_cache = cu2rec_ratings_load_binary(cache.c_str(), &r) == CU2REC_OK;
+    }
+    if (!from_cache) {
+        check(cu2rec_ratings_read_csv(path.c_str(), &r));
+        if (want_cache && *want_cache == '1') (void)cu2rec_ratings_save_binary(r, cache.c_str());  // best effort
+    }
     HostCsr m;
     try {
         check(cu2rec_ratings_info(r, &m.nnz, &m.rows, &m.cols, &m.global_bias));

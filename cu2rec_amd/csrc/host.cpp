@@ -16,6 +16,7 @@
 #include <fstream>
 #include <random>
 #include <sstream>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -90,6 +91,83 @@ struct Cursor {
 
 }  // namespace
 
+struct ParsedChunk {
+    std::vector<int> user, item;
+    std::vector<float> rating;
+    int rows = 0, cols = 0;
+    bool clean = true;  // every record sat alone on its line and the chunk was consumed to its end
+};
+
+// One record per line, strictly: used by the threaded reader, which may only split the text at line starts.
+// Anything else (records spanning lines, trailing junk) marks the chunk unclean and the caller falls back to
+// the sequential reader, whose behaviour is the reference's.
+static void parse_lines(const char *begin, const char *end, ParsedChunk &out) {
+    Cursor cur{begin, end};
+    int u, i;
+    float r;
+    while (true) {
+        cur.skip_space();
+        if (cur.p >= cur.end) return;
+        const char *line = cur.p;
+        if (!(cur.read_int(u) && cur.read_char() && cur.read_int(i) && cur.read_char() && cur.read_float(r))) {
+            out.clean = false;
+            return;
+        }
+        for (const char *q = line; q < cur.p; ++q)
+            if (*q == '\n') {
+                out.clean = false;
+                return;
+            }
+        while (cur.p < cur.end && (*cur.p == ' ' || *cur.p == '\t' || *cur.p == '\r')) ++cur.p;
+        if (cur.p < cur.end && *cur.p != '\n') {
+            out.clean = false;
+            return;
+        }
+        out.user.push_back(u - 1);
+        out.item.push_back(i - 1);
+        out.rating.push_back(r);
+        out.rows = std::max(out.rows, u);
+        out.cols = std::max(out.cols, i);
+    }
+}
+
+static bool read_ratings_threaded(const char *begin, const char *end, unsigned n_threads, RatingsFile &out) {
+    std::vector<const char *> cut(n_threads + 1, end);
+    cut[0] = begin;
+    for (unsigned k = 1; k < n_threads; ++k) {
+        const char *p = begin + (static_cast<size_t>(end - begin) * k) / n_threads;
+        while (p < end && *p != '\n') ++p;
+        cut[k] = p < end ? p + 1 : end;
+    }
+    std::vector<ParsedChunk> chunks(n_threads);
+    std::vector<std::thread> pool;
+    for (unsigned k = 0; k < n_threads; ++k)
+        pool.emplace_back([&, k] {
+            chunks[k].user.reserve(static_cast<size_t>(cut[k + 1] - cut[k]) / 12 + 16);
+            parse_lines(cut[k], cut[k + 1], chunks[k]);
+        });
+    for (auto &t : pool) t.join();
+    size_t total = 0;
+    for (const auto &c : chunks) {
+        if (!c.clean) return false;
+        total += c.user.size();
+    }
+    out.user.reserve(total);
+    out.item.reserve(total);
+    out.rating.reserve(total);
+    for (const auto &c : chunks) {
+        out.user.insert(out.user.end(), c.user.begin(), c.user.end());
+        out.item.insert(out.item.end(), c.item.begin(), c.item.end());
+        out.rating.insert(out.rating.end(), c.rating.begin(), c.rating.end());
+        out.rows = std::max(out.rows, c.rows);
+        out.cols = std::max(out.cols, c.cols);
+    }
+    double sum = 0.0;  // in file order, like the reference's running sum (util.cu:36)
+    for (float r : out.rating) sum += r;
+    out.global_bias = static_cast<float>(sum / (1.0 * out.user.size()));
+    return true;
+}
+
 // readCSV, util.cu:17-45
 static RatingsFile read_ratings_csv(const char *path) {
     const std::string text = slurp(path);
@@ -98,6 +176,13 @@ static RatingsFile read_ratings_csv(const char *path) {
     for (int k = 0; k < 1000 && cur.p < cur.end; ++k)
         if (*cur.p++ == '\n') break;
     RatingsFile out;
+    // large files: parse line-aligned chunks on all host cores (ML-20M: 20 M records)
+    const size_t body = static_cast<size_t>(cur.end - cur.p);
+    unsigned n_threads = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    if (const char *env = std::getenv("CU2REC_READER_THREADS")) n_threads = std::max(1, std::atoi(env));
+    n_threads = static_cast<unsigned>(std::min<size_t>(n_threads, body / (1u << 20) + 1));
+    if (n_threads > 1 && read_ratings_threaded(cur.p, cur.end, n_threads, out)) return out;
+    out = RatingsFile();
     const size_t guess = static_cast<size_t>(cur.end - cur.p) / 12 + 16;
     out.user.reserve(guess);
     out.item.reserve(guess);
@@ -226,6 +311,63 @@ int cu2rec_ratings_read_csv(const char *path, cu2rec_ratings **out) {
         *out = nullptr;
         auto holder = new cu2rec_ratings{read_ratings_csv(path)};
         *out = holder;
+    });
+}
+
+// Binary cache of a parsed ratings file: header + the three COO columns, native endianness.
+namespace {
+struct CacheHeader {
+    char magic[8];
+    int32_t n, rows, cols;
+    float global_bias;
+};
+const char kCacheMagic[8] = {'C', 'U', '2', 'R', 'C', 'O', 'O', '1'};
+}  // namespace
+
+int cu2rec_ratings_save_binary(const cu2rec_ratings *r, const char *path) {
+    return guarded([&] {
+        require(r && path, "null argument");
+        FILE *fp = std::fopen(path, "wb");
+        if (!fp) fail(CU2REC_EIO, std::string("cannot write ") + path);
+        CacheHeader h;
+        std::memcpy(h.magic, kCacheMagic, 8);
+        h.n = static_cast<int32_t>(r->file.user.size());
+        h.rows = r->file.rows;
+        h.cols = r->file.cols;
+        h.global_bias = r->file.global_bias;
+        bool ok = std::fwrite(&h, sizeof(h), 1, fp) == 1;
+        const size_t n = r->file.user.size();
+        ok = ok && std::fwrite(r->file.user.data(), sizeof(int), n, fp) == n;
+        ok = ok && std::fwrite(r->file.item.data(), sizeof(int), n, fp) == n;
+        ok = ok && std::fwrite(r->file.rating.data(), sizeof(float), n, fp) == n;
+        std::fclose(fp);
+        if (!ok) fail(CU2REC_EIO, std::string("short write to ") + path);
+    });
+}
+
+int cu2rec_ratings_load_binary(const char *path, cu2rec_ratings **out) {
+    return guarded([&] {
+        require(path && out, "null argument");
+        *out = nullptr;
+        FILE *fp = std::fopen(path, "rb");
+        if (!fp) fail(CU2REC_EIO, std::string("cannot open ") + path);
+        CacheHeader h;
+        RatingsFile f;
+        bool ok = std::fread(&h, sizeof(h), 1, fp) == 1 && std::memcmp(h.magic, kCacheMagic, 8) == 0 && h.n >= 0;
+        if (ok) {
+            const size_t n = static_cast<size_t>(h.n);
+            f.user.resize(n);
+            f.item.resize(n);
+            f.rating.resize(n);
+            ok = std::fread(f.user.data(), sizeof(int), n, fp) == n && std::fread(f.item.data(), sizeof(int), n, fp) == n &&
+                 std::fread(f.rating.data(), sizeof(float), n, fp) == n;
+            f.rows = h.rows;
+            f.cols = h.cols;
+            f.global_bias = h.global_bias;
+        }
+        std::fclose(fp);
+        if (!ok) fail(CU2REC_EIO, std::string("not a cu2rec ratings cache: ") + path);
+        *out = new cu2rec_ratings{std::move(f)};
     });
 }
 

@@ -84,8 +84,14 @@ typedef struct cu2rec_ratings cu2rec_ratings; /* opaque, host memory */
 
 /* "userId,itemId,rating" with one header line; ids 1-based, converted to 0-based.  rows/cols
  * = max id seen, global_bias = float(double sum / n).  A file that cannot be opened is
- * CU2REC_EIO (the reference prints "ERROR: The file isnt open." and returns nothing). */
+ * CU2REC_EIO (the reference prints "ERROR: The file isnt open." and returns nothing).
+ * Files above ~1 MB whose records sit one per line are parsed on all host cores (CU2REC_READER_THREADS
+ * overrides the count); anything else takes the sequential path, whose record grammar is the reference's
+ * (`int char int char float` separated by arbitrary whitespace, first malformed record ends the file). */
 int cu2rec_ratings_read_csv(const char *path, cu2rec_ratings **out);
+/* Binary cache of a parsed file (header + three COO columns): loading it replaces the text parse. */
+int cu2rec_ratings_save_binary(const cu2rec_ratings *r, const char *path);
+int cu2rec_ratings_load_binary(const char *path, cu2rec_ratings **out);
 int cu2rec_ratings_info(const cu2rec_ratings *r, int *n, int *rows, int *cols, float *global_bias);
 /* raw COO views (length n), valid until cu2rec_ratings_free */
 int cu2rec_ratings_view(const cu2rec_ratings *r, const int **user, const int **item, const float **rating);

@@ -139,3 +139,51 @@ def test_shard_plan_and_slice():
     assert s.indptr.tolist() == [0, 3, 6, 9] and s.nnz == 9 and s.indices.tolist() == m.indices[7:16].tolist()
     whole = [m.slice_users(a, b) for a, b in zip(cu.shard_plan(m.rows, 4)[:-1], cu.shard_plan(m.rows, 4)[1:])]
     assert sum(w.nnz for w in whole) == m.nnz
+
+
+def test_threaded_reader_binary_cache_and_fallback(tmp_path):
+    """files above 1 MB are parsed on several threads (same result as the sequential grammar and as
+    the oracle's fscanf restatement); a record that spans lines forces the sequential path; the binary cache round-trips."""
+    import ctypes as C
+    rng = np.random.RandomState(4)
+    n_users = 3000
+    rows = []
+    for u in range(1, n_users + 1):
+        for i in np.sort(rng.choice(5000, rng.randint(20, 60), replace=False)) + 1:
+            rows.append("%d,%d,%s" % (u, i, rng.choice(["0.5", "3", "4.5", "5.0", "2.5"])))
+    p = tmp_path / "big.csv"
+    p.write_text("userId,itemId,rating\n" + "\n".join(rows))  # no trailing newline
+    assert p.stat().st_size > (1 << 20)
+    want = orc.read_csv(str(p))
+    for threads in ("1", "3", "8"):
+        os.environ["CU2REC_READER_THREADS"] = threads
+        got = cu.createSparseMatrix(str(p))
+        np.testing.assert_array_equal(got.indptr, want.indptr)
+        np.testing.assert_array_equal(got.indices, want.indices)
+        np.testing.assert_array_equal(got.data, want.data)
+        assert np.float32(got.global_bias) == np.float32(want.global_bias)
+    # a record broken over two lines in the middle: only the sequential grammar accepts it
+    broken = rows[: len(rows) // 2] + ["%s,\n%s" % tuple(rows[len(rows) // 2].split(",", 1))] + rows[len(rows) // 2 + 1:]
+    q = tmp_path / "broken.csv"
+    q.write_text("userId,itemId,rating\n" + "\n".join(broken) + "\n")
+    os.environ["CU2REC_READER_THREADS"] = "4"
+    got = cu.createSparseMatrix(str(q))
+    np.testing.assert_array_equal(got.indices, want.indices)
+    del os.environ["CU2REC_READER_THREADS"]
+    # binary cache
+    L = cu.lib()
+    h, h2 = C.c_void_p(), C.c_void_p()
+    assert L.cu2rec_ratings_read_csv(str(p).encode(), C.byref(h)) == 0
+    assert L.cu2rec_ratings_save_binary(h, str(tmp_path / "big.bin").encode()) == 0
+    assert L.cu2rec_ratings_load_binary(str(tmp_path / "big.bin").encode(), C.byref(h2)) == 0
+    n1, n2, gb1, gb2 = C.c_int(), C.c_int(), C.c_float(), C.c_float()
+    L.cu2rec_ratings_info(h, C.byref(n1), None, None, C.byref(gb1))
+    L.cu2rec_ratings_info(h2, C.byref(n2), None, None, C.byref(gb2))
+    assert n1.value == n2.value == len(rows) and gb1.value == gb2.value
+    indptr, indices, data = np.zeros(n_users + 1, np.int32), np.zeros(len(rows), np.int32), np.zeros(len(rows), np.float32)
+    assert L.cu2rec_csr_build(h2, n_users, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p),
+                              data.ctypes.data_as(C.c_void_p)) == 0
+    np.testing.assert_array_equal(indices, want.indices)
+    L.cu2rec_ratings_free(h)
+    L.cu2rec_ratings_free(h2)
+    assert L.cu2rec_ratings_load_binary(str(p).encode(), C.byref(h2)) == -2  # a text file is not a cache
