@@ -22,6 +22,10 @@
 #include "sampler.hpp"
 #include "sgd_device.hpp"
 
+#ifndef CU2REC_STREAM_P
+#define CU2REC_STREAM_P 0  // 1: non-temporal loads / stores for the user rows of the Hogwild kernel (A/B builds)
+#endif
+
 namespace cu2rec {
 
 namespace {
@@ -56,10 +60,18 @@ __global__ __launch_bounds__(kBlock) void sgd_hogwild_kernel(SgdArgs a) {
     for (int x = group; x < a.n_rows; x += n_groups) {
         const int low = a.indptr[x], high = a.indptr[x + 1];
         if (low == high) continue;  // sgd.cu:34: users without ratings are skipped
+#if CU2REC_STREAM_P
+        Row<J> p = load_row_stream<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+#else
         Row<J> p = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+#endif
         float ub = a.user_bias[x];
         for (int k = 0; k < a.iters; ++k) sgd_one<J>(a, x, low, high, a.iter0 + static_cast<uint64_t>(k), lane, p, ub);
+#if CU2REC_STREAM_P
+        store_row_stream<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
+#else
         store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
+#endif
         if (lane == 0) a.user_bias[x] = ub;
     }
 }

@@ -69,6 +69,41 @@ __device__ __forceinline__ float slot_dot(const float4 &q, const float4 &p) {
     return s;
 }
 
+typedef float vec4f __attribute__((ext_vector_type(4)));  // the builtin wants a native vector type
+
+// Streaming variants for rows that are touched once per launch (the user rows of the Hogwild kernel): the
+// non-temporal hint keeps them from displacing the item rows, which ARE re-read, in the XCD's L2.
+template <int J>
+__device__ __forceinline__ Row<J> load_row_stream(const float *__restrict__ base, size_t row, int ld, int nslots, int lane) {
+    const float4 *p = reinterpret_cast<const float4 *>(base + row * static_cast<size_t>(ld));
+    Row<J> r;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int slot = lane + kGroup * j;
+        if (slot < nslots) {
+            const vec4f v = __builtin_nontemporal_load(reinterpret_cast<const vec4f *>(&p[slot]));
+            r.v[j] = make_float4(v.x, v.y, v.z, v.w);
+        } else {
+            r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    return r;
+}
+
+template <int J>
+__device__ __forceinline__ void store_row_stream(float *__restrict__ base, size_t row, int ld, int nslots, int lane,
+                                                 const Row<J> &r) {
+    float4 *p = reinterpret_cast<float4 *>(base + row * static_cast<size_t>(ld));
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int slot = lane + kGroup * j;
+        if (slot < nslots) {
+            const vec4f v = {r.v[j].x, r.v[j].y, r.v[j].z, r.v[j].w};
+            __builtin_nontemporal_store(v, reinterpret_cast<vec4f *>(&p[slot]));
+        }
+    }
+}
+
 // util.cu:199-204 get_prediction in the kernels' canonical order ("TREE16" in the oracle):
 //   slot partial  s_k   = fmaf chain over the 4 floats of slot k
 //   lane total    t_l   = ((s_l + s_{l+16}) + s_{l+32}) + ...        (l = 0..15)
