@@ -22,6 +22,9 @@
 #include "sampler.hpp"
 #include "sgd_device.hpp"
 
+#ifndef CU2REC_ABLATE_SAMPLER
+#define CU2REC_ABLATE_SAMPLER 0  // timing-only builds (see sgd_one); never set in the shipped library
+#endif
 #ifndef CU2REC_STREAM_P
 #define CU2REC_STREAM_P 0  // 1: non-temporal loads / stores for the user rows of the Hogwild kernel (A/B builds)
 #endif
@@ -37,9 +40,21 @@ using namespace dev;
 template <int J>
 __device__ __forceinline__ void sgd_one(const SgdArgs &a, int x, int low, int high, uint64_t it, int lane,
                                         Row<J> &p, float &ub) {
+#if CU2REC_ABLATE_SAMPLER == 1
+    // timing only: no Philox, no CSR gathers -- a cheap in-register hash picks the item
+    const int y = static_cast<int>((static_cast<uint32_t>(x) * 2654435761u + static_cast<uint32_t>(it) * 40503u) % 26744u);
+    const float rating = 3.5f;
+    (void)low; (void)high;
+#elif CU2REC_ABLATE_SAMPLER == 2
+    // timing only: Philox kept, CSR gathers dropped
+    const int y_i = sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + x), it, low, high);
+    const int y = static_cast<int>(static_cast<uint32_t>(y_i) * 2654435761u % 26744u);
+    const float rating = 3.5f;
+#else
     const int y_i = sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + x), it, low, high);  // sgd.cu:36-37
     const int y = a.indices[y_i];
     const float rating = a.data[y_i];
+#endif
     Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
     const float ib = a.item_bias[y];
     const float err = rating - predict<J>(p, q, ub, ib, a.global_bias);  // sgd.cu:45
