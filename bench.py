@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--factors", type=int, default=100)
     ap.add_argument("--mode", default="hogwild", choices=["hogwild", "serial", "ordered"])
     ap.add_argument("--sync-every", type=int, default=0, help="steps between item-factor all-reduces (0 = one epoch)")
-    ap.add_argument("--merge", default="mean", choices=["mean", "sum"])
+    ap.add_argument("--merge", default="mean", choices=["mean", "sum", "weighted"])
     ap.add_argument("--seed", type=int, default=20240917)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-samples", type=int, default=200)
@@ -201,7 +201,8 @@ def main():
     eng = Engine(train.rows, train.cols, f, train.global_bias, device=device)
     d_train, d_test = DeviceRatings(train, device), DeviceRatings(test, device)
     # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the global population
-    job = ShardedSGD(eng, d_train, user_offset=rank * train.rows, sync_every=sync_every, merge=args.merge)
+    rates = cu.api.item_update_rates(train) if args.merge == "weighted" else None
+    job = ShardedSGD(eng, d_train, user_offset=rank * train.rows, sync_every=sync_every, merge=args.merge, item_rates=rates)
     if args.iters_per_launch > 1:
         cu.lib().cu2rec_hogwild_iters_per_launch(args.iters_per_launch)
     mode = {"hogwild": cu.SGD_HOGWILD, "serial": cu.SGD_SERIAL, "ordered": cu.SGD_ORDERED}[args.mode]

@@ -182,6 +182,13 @@ def sampler_index(seed, user, iteration, low, high):
     return lib().cu2rec_sampler_index(seed, user, iteration, low, high)
 
 
+def item_update_rates(csr):
+    """Expected SGD updates per iteration on each item from the users of `csr` (sum over raters of 1 / degree)."""
+    out = np.zeros(csr.cols, np.float64)
+    check(lib().cu2rec_item_update_rates(_ptr(csr.indptr), _ptr(csr.indices), csr.rows, csr.cols, _ptr(out)))
+    return out
+
+
 def shard_plan(rows, nranks):
     out = np.zeros(nranks + 1, np.int32)
     check(lib().cu2rec_shard_plan(rows, nranks, _ptr(out)))

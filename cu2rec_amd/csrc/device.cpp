@@ -485,6 +485,17 @@ int cu2rec_items_delta_pack(const float *Q, const float *item_bias, const float 
     });
 }
 
+int cu2rec_items_delta_pack_weighted(const float *Q, const float *item_bias, const float *Q_base, const float *ib_base,
+                                     const float *item_weight, int n_cols, int ldq, float *buf, void *stream) {
+    return guarded([&] {
+        require(Q && item_bias && Q_base && ib_base && item_weight && buf && n_cols >= 0 && ldq > 0, "bad argument");
+        require_device();
+        if (n_cols == 0) return;
+        launch_items_delta_pack_weighted(Q, item_bias, Q_base, ib_base, item_weight, n_cols, ldq, buf, as_stream(stream));
+        CU2REC_HIP(hipGetLastError());
+    });
+}
+
 int cu2rec_items_delta_apply(float *Q, float *item_bias, float *Q_base, float *ib_base, int n_cols, int ldq,
                              const float *buf, float scale, void *stream) {
     return guarded([&] {

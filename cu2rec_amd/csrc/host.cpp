@@ -471,6 +471,23 @@ int cu2rec_shard_plan(int rows, int nranks, int *user_begin) {
     });
 }
 
+int cu2rec_item_update_rates(const int *indptr, const int *indices, int n_rows, int n_cols, double *rate) {
+    return guarded([&] {
+        require(indptr && rate && n_rows >= 0 && n_cols >= 0, "bad argument");
+        std::fill(rate, rate + n_cols, 0.0);
+        for (int u = 0; u < n_rows; ++u) {
+            const int lo = indptr[u], hi = indptr[u + 1];
+            if (hi <= lo) continue;
+            require(indices != nullptr, "indices is null");
+            const double w = 1.0 / (hi - lo);
+            for (int k = lo; k < hi; ++k) {
+                require(indices[k] >= 0 && indices[k] < n_cols, "item id out of range");
+                rate[indices[k]] += w;
+            }
+        }
+    });
+}
+
 int cu2rec_csr_slice(const int *indptr, int rows, int u0, int u1, int *indptr_out, int *offset_out, int *nnz_out) {
     return guarded([&] {
         require(indptr && indptr_out, "null argument");

@@ -220,6 +220,20 @@ __global__ __launch_bounds__(kBlock) void items_delta_pack_kernel(const float *_
         buf[i] = i < nq ? Q[i] - Q_base[i] : ib[i - nq] - ib_base[i - nq];
 }
 
+__global__ __launch_bounds__(kBlock) void items_delta_pack_weighted_kernel(const float *__restrict__ Q,
+                                                                           const float *__restrict__ ib,
+                                                                           const float *__restrict__ Q_base,
+                                                                           const float *__restrict__ ib_base,
+                                                                           const float *__restrict__ weight, size_t nq,
+                                                                           int n_cols, int ldq, float *__restrict__ buf) {
+    const size_t total = nq + static_cast<size_t>(n_cols);
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        if (i < nq) buf[i] = weight[i / ldq] * (Q[i] - Q_base[i]);
+        else buf[i] = weight[i - nq] * (ib[i - nq] - ib_base[i - nq]);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void items_delta_apply_kernel(float *__restrict__ Q, float *__restrict__ ib,
                                                                    float *__restrict__ Q_base,
                                                                    float *__restrict__ ib_base, size_t nq, int n_cols,
@@ -311,6 +325,14 @@ void launch_items_delta_pack(const float *Q, const float *ib, const float *Q_bas
     const int blocks = blocks_for(nq + n_cols, kBlock * 4, 4096);
     hipLaunchKernelGGL(items_delta_pack_kernel, dim3(blocks), dim3(kBlock), 0, stream, Q, ib, Q_base, ib_base, nq,
                        n_cols, buf);
+}
+
+void launch_items_delta_pack_weighted(const float *Q, const float *ib, const float *Q_base, const float *ib_base,
+                                      const float *weight, int n_cols, int ldq, float *buf, hipStream_t stream) {
+    const size_t nq = static_cast<size_t>(n_cols) * ldq;
+    const int blocks = blocks_for(nq + n_cols, kBlock * 4, 4096);
+    hipLaunchKernelGGL(items_delta_pack_weighted_kernel, dim3(blocks), dim3(kBlock), 0, stream, Q, ib, Q_base, ib_base,
+                       weight, nq, n_cols, ldq, buf);
 }
 
 void launch_items_delta_apply(float *Q, float *ib, float *Q_base, float *ib_base, int n_cols, int ldq,

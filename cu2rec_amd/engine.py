@@ -111,9 +111,15 @@ class Engine:
         self.item_bias_base = self.item_bias.clone()
         self.exchange = torch.empty(self.Q.numel() + self.item_bias.numel(), dtype=torch.float32, device=self.device)
 
-    def pack_item_delta(self):
-        """exchange <- [Q - Q_base | item_bias - item_bias_base] (device kernel)."""
+    def pack_item_delta(self, item_weight=None):
+        """exchange <- [Q - Q_base | item_bias - item_bias_base] (device kernel), optionally times a per-item weight."""
         from ._lib import check
+        if item_weight is not None:
+            check(lib().cu2rec_items_delta_pack_weighted(self.Q.data_ptr(), self.item_bias.data_ptr(),
+                                                         self.Q_base.data_ptr(), self.item_bias_base.data_ptr(),
+                                                         item_weight.data_ptr(), self.item_bias.numel(), self.ld,
+                                                         self.exchange.data_ptr(), _stream_ptr()))
+            return self.exchange
         check(lib().cu2rec_items_delta_pack(self.Q.data_ptr(), self.item_bias.data_ptr(), self.Q_base.data_ptr(),
                                             self.item_bias_base.data_ptr(), self.item_bias.numel(), self.ld,
                                             self.exchange.data_ptr(), _stream_ptr()))

@@ -18,7 +18,7 @@ def main(argv=None):
     ap.add_argument("-c", dest="config", default=None)
     ap.add_argument("-m", dest="mode", default="hogwild", choices=["hogwild", "ordered", "serial"])
     ap.add_argument("--sync-every", type=int, default=0)
-    ap.add_argument("--merge", default="mean", choices=["mean", "sum"])
+    ap.add_argument("--merge", default="weighted", choices=["mean", "sum", "weighted"])
     ap.add_argument("train")
     ap.add_argument("test")
     args = ap.parse_args(argv)

@@ -32,23 +32,45 @@ def plan_users(n_users, world_size):
 
 
 class ShardedSGD:
-    def __init__(self, engine, ratings, user_offset=0, sync_every=100, merge="mean", group=None):
-        if merge not in ("mean", "sum"):
-            raise ValueError("merge must be 'mean' or 'sum'")
+    def __init__(self, engine, ratings, user_offset=0, sync_every=100, merge="mean", group=None, item_rates=None):
+        """merge: how the replicas' item deltas are combined at an exchange --
+             "mean"      delta = (1/N) sum_k delta_k       right when every rank sees every item about equally often
+             "sum"       delta = sum_k delta_k             right when every item is updated by (almost) one rank only
+             "weighted"  delta[y] = sum_k w_k[y] delta_k[y], w_k[y] = rate_k[y] / sum_j rate_j[y] with rate_k[y] the
+                         expected updates per iteration of rank k's users on item y (item_rates, a float64 array of
+                         n_items from api.item_update_rates(shard)): a per-item average that leaves items touched by
+                         one rank at full step and averages the shared ones."""
+        if merge not in ("mean", "sum", "weighted"):
+            raise ValueError("merge must be 'mean', 'sum' or 'weighted'")
         self.engine, self.ratings, self.user_offset = engine, ratings, int(user_offset)
         self.sync_every, self.merge, self.group = max(int(sync_every), 1), merge, group
         self.rank, self.world_size = world()
         self.since_sync = 0
         self.exchanges = 0
+        self.item_weight = None
         if self.world_size > 1:
             engine.snapshot_items()
+            if merge == "weighted":
+                if item_rates is None:
+                    raise ValueError("merge='weighted' needs item_rates")
+                mine = torch.as_tensor(item_rates, dtype=torch.float64)
+                total = mine.clone()
+                dev = getattr(engine, "device", None)
+                if dev is not None and dist.get_backend(group) == "nccl":
+                    total = total.to(dev)
+                dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+                total = total.cpu()
+                w = torch.where(total > 0, mine / total.clamp_min(1e-300), torch.full_like(mine, 1.0 / self.world_size))
+                self.item_weight = w.to(torch.float32)
+                if dev is not None:
+                    self.item_weight = self.item_weight.to(dev)
 
     def exchange(self):
         """All-reduce the item-factor deltas and rebase every replica on the merged result."""
         self.since_sync = 0
         if self.world_size == 1:
             return
-        buf = self.engine.pack_item_delta()
+        buf = self.engine.pack_item_delta(self.item_weight) if self.merge == "weighted" else self.engine.pack_item_delta()
         if buf.is_cuda and dist.get_backend(self.group) != "nccl":
             # debugging aid (e.g. two ranks sharing one GPU under gloo): stage through the host
             host = buf.cpu()
@@ -56,7 +78,7 @@ class ShardedSGD:
             buf.copy_(host)
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        self.engine.apply_item_delta(1.0 / self.world_size if self.merge == "mean" else 1.0)
+        self.engine.apply_item_delta(1.0 / self.world_size if self.merge == "mean" else 1.0)  # weighted / sum: 1
         self.since_sync = 0
         self.exchanges += 1
 
@@ -121,7 +143,8 @@ def train_sharded(train, test, cfg, mode=api.SGD_HOGWILD, sync_every=0, merge="m
         eng, d_tr, d_te = engine_factory(u1 - u0, train.cols, f, train.global_bias, P0, ub0, tr, te)
     users_active = float(np.count_nonzero(np.diff(train.indptr)))
     every = sync_every or max(1, int(round(train.nnz / max(users_active, 1.0))))
-    job = ShardedSGD(eng, d_tr, user_offset=u0, sync_every=every, merge=merge)
+    rates = api.item_update_rates(tr) if merge == "weighted" else None
+    job = ShardedSGD(eng, d_tr, user_offset=u0, sync_every=every, merge=merge, item_rates=rates)
 
     total = cfg.total_iterations
     losses = np.full(max(total, 1), np.nan, np.float32)

@@ -267,6 +267,13 @@ int cu2rec_csr_slice(const int *indptr, int rows, int u0, int u1, int *indptr_ou
  * between them the caller all-reduces `buf` (RCCL via torch.distributed or ncclAllReduce). */
 int cu2rec_items_delta_pack(const float *Q, const float *item_bias, const float *Q_base, const float *ib_base,
                             int n_cols, int ldq, float *buf, void *stream);
+/* Same with a per-item weight (device, n_cols floats) applied to the item's delta row and bias delta: ranks pack
+ * w_k[y] * delta_k[y] with sum_k w_k[y] == 1, all-reduce(SUM), apply with scale 1 -- a per-item weighted average. */
+int cu2rec_items_delta_pack_weighted(const float *Q, const float *item_bias, const float *Q_base, const float *ib_base,
+                                     const float *item_weight, int n_cols, int ldq, float *buf, void *stream);
+/* Expected number of SGD updates per iteration that the rows of a host CSR make on each item:
+ * rate[y] = sum over users u that rated y of 1 / degree(u)   (each user samples uniformly among its ratings). */
+int cu2rec_item_update_rates(const int *indptr, const int *indices, int n_rows, int n_cols, double *rate);
 int cu2rec_items_delta_apply(float *Q, float *item_bias, float *Q_base, float *ib_base, int n_cols, int ldq,
                              const float *buf, float scale, void *stream);
 

@@ -56,8 +56,12 @@ class OracleEngine:
     def snapshot_items(self):
         self.Q_base, self.ib_base = self.Q.copy(), self.ib.copy()
 
-    def pack_item_delta(self):
-        self._buf = torch.from_numpy(np.concatenate([(self.Q - self.Q_base).ravel(), self.ib - self.ib_base]))
+    def pack_item_delta(self, item_weight=None):
+        dQ, dib = self.Q - self.Q_base, self.ib - self.ib_base
+        if item_weight is not None:
+            w = item_weight.numpy().astype(np.float32)
+            dQ, dib = dQ * w[:, None], dib * w
+        self._buf = torch.from_numpy(np.concatenate([dQ.ravel(), dib]).astype(np.float32))
         return self._buf
 
     def apply_item_delta(self, scale):
@@ -194,3 +198,50 @@ def test_train_sharded_two_ranks_gloo(tmp_path):
     assert float(a["lr"]) == float(b["lr"])
     checked = [i for i in range(12) if not np.isnan(a["losses"][i])]
     assert checked == [0, 3, 7, 11] and a["losses"][11] < a["losses"][0]
+
+
+def _weighted_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr, _ = synth.make_ratings(80, 25, 900, min_degree=2, seed=5)
+    f = 6
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    bounds = plan_users(tr.rows, world)
+    u0, u1 = bounds[rank], bounds[rank + 1]
+    shard = tr.slice_users(u0, u1)
+    eng = OracleEngine(u1 - u0, tr.cols, f, tr.global_bias, P[u0:u1], Q, ub[u0:u1], ib)
+    job = ShardedSGD(eng, shard, user_offset=u0, sync_every=5, merge="weighted", item_rates=cu.api.item_update_rates(shard))
+    job.run(HYPER, 42, 0, 5, cu.SGD_HOGWILD)
+    np.savez(os.path.join(out_dir, "w%d.npz" % rank), Q=eng.Q, ib=eng.ib, w=job.item_weight.numpy())
+    dist.destroy_process_group()
+
+
+def test_weighted_merge_two_ranks_gloo(tmp_path):
+    """merge='weighted': per-item weights rate_k / sum rate (they sum to one over ranks), result = Q_base + sum_k w_k delta_k."""
+    world, port = 2, 33000 + os.getpid() % 2000
+    mp.spawn(_weighted_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = (np.load(str(tmp_path / ("w%d.npz" % k))) for k in range(2))
+    np.testing.assert_allclose(a["w"] + b["w"], 1.0, atol=1e-6)
+    np.testing.assert_array_equal(a["Q"], b["Q"])
+    tr, _ = synth.make_ratings(80, 25, 900, min_degree=2, seed=5)
+    f = 6
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    bounds = plan_users(tr.rows, world)
+    deltas, rates = [], []
+    for k in range(world):
+        sh = tr.slice_users(bounds[k], bounds[k + 1])
+        e = OracleEngine(bounds[k + 1] - bounds[k], tr.cols, f, tr.global_bias, P[bounds[k]:bounds[k + 1]], Q,
+                         ub[bounds[k]:bounds[k + 1]], ib)
+        e.sgd(sh, HYPER, 42, 0, 5, cu.SGD_HOGWILD, True, bounds[k])
+        deltas.append(e.Q - Q)
+        rates.append(cu.api.item_update_rates(sh))
+    tot = rates[0] + rates[1]
+    w = [np.where(tot > 0, r / np.maximum(tot, 1e-300), 0.5).astype(np.float32) for r in rates]
+    want = Q + sum(wk[:, None] * d for wk, d in zip(w, deltas))
+    np.testing.assert_allclose(a["Q"], want, atol=1e-6)
+    # an item rated by one rank only keeps that rank's full step
+    only0 = (rates[0] > 0) & (rates[1] == 0)
+    if only0.any():
+        np.testing.assert_allclose(a["Q"][only0], (Q + deltas[0])[only0], atol=1e-6)

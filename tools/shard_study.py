@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""How should N user shards reconcile their item factors?  Emulates N ranks on ONE GPU (N engines, one device,
+shards run one after the other; the exchange arithmetic is done here with torch ops -- a study tool, not the
+product path, which uses one process per GPU and an RCCL all-reduce) and compares the test RMSE after the same
+number of iterations with the unsharded run, for merge in {mean, sum, weighted} and several sync periods.
+
+usage: tools/shard_study.py [--workload ml-20m] [--factors 100] [--iters 1000] [--shards 2,8] [--sync 16,115]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="ml-20m")
+    ap.add_argument("--factors", type=int, default=100)
+    ap.add_argument("--iters", type=int, default=1000)
+    ap.add_argument("--shards", default="2,8")
+    ap.add_argument("--sync", default="16,115")
+    ap.add_argument("--mode", default="hogwild")
+    args = ap.parse_args()
+    import torch
+
+    import bench
+    import cu2rec_amd as cu
+    from cu2rec_amd.engine import DeviceRatings, Engine
+    from cu2rec_amd.parallel import plan_users
+
+    train, test = bench.load_dataset(args.workload, 20240917, 0, lambda: None)
+    f, hyper = args.factors, (0.01, 0.02, 0.02, 0.02, 0.02)
+    dev = torch.device("cuda", 0)
+    P0 = cu.initialize_normal_array(train.rows * f, f).reshape(train.rows, f)
+    ub0 = cu.initialize_normal_array(train.rows, f)
+
+    def test_rmse(engines, bounds):
+        sa = ss = 0.0
+        for e, (u0, u1) in zip(engines, bounds):
+            out = e.loss(DeviceRatings(test.slice_users(u0, u1), dev))
+            sa, ss = sa + out["sum_abs"], ss + out["sum_sq"]
+        return (ss / test.nnz) ** 0.5
+
+    results = []
+    base = Engine(train.rows, train.cols, f, train.global_bias, device=dev)
+    base.sgd(DeviceRatings(train, dev), hyper, 42, 0, args.iters, args.mode)
+    ref = test_rmse([base], [(0, train.rows)])
+    results.append({"shards": 1, "rmse": ref})
+    print("N=1 rmse %.5f" % ref, flush=True)
+    del base
+    for n in [int(v) for v in args.shards.split(",")]:
+        b = plan_users(train.rows, n)
+        bounds = list(zip(b[:-1], b[1:]))
+        shards = [train.slice_users(u0, u1) for u0, u1 in bounds]
+        rates = np.stack([cu.api.item_update_rates(s) for s in shards])
+        tot = rates.sum(0)
+        weights = torch.tensor(np.where(tot > 0, rates / np.maximum(tot, 1e-300), 1.0 / n), dtype=torch.float32, device=dev)
+        for sync in [int(v) for v in args.sync.split(",")]:
+            for merge in ("mean", "sum", "weighted"):
+                engines = [Engine(u1 - u0, train.cols, f, train.global_bias, P=P0[u0:u1], user_bias=ub0[u0:u1], device=dev)
+                           for u0, u1 in bounds]
+                d = [DeviceRatings(s, dev) for s in shards]
+                Qb, ibb = engines[0].Q.clone(), engines[0].item_bias.clone()
+                it = 0
+                while it < args.iters:
+                    k = min(sync, args.iters - it)
+                    for e, dr, (u0, _) in zip(engines, d, bounds):
+                        e.sgd(dr, hyper, 42, it, k, args.mode, True, u0)
+                    it += k
+                    dQ = torch.stack([e.Q - Qb for e in engines])
+                    dib = torch.stack([e.item_bias - ibb for e in engines])
+                    if merge == "mean":
+                        Qb, ibb = Qb + dQ.mean(0), ibb + dib.mean(0)
+                    elif merge == "sum":
+                        Qb, ibb = Qb + dQ.sum(0), ibb + dib.sum(0)
+                    else:
+                        Qb = Qb + (weights[:, :, None] * dQ[:, :train.cols]).sum(0)
+                        ibb = ibb + (weights * dib[:, :train.cols]).sum(0)
+                    for e in engines:
+                        e.Q.copy_(Qb)
+                        e.item_bias.copy_(ibb)
+                r = test_rmse(engines, bounds)
+                results.append({"shards": n, "sync_every": sync, "merge": merge, "rmse": r, "delta_vs_n1": r - ref})
+                print("N=%d sync=%d merge=%-8s rmse %.5f (%+.5f vs N=1)" % (n, sync, merge, r, r - ref), flush=True)
+                del engines, d
+    print(json.dumps({"workload": args.workload, "f": f, "iters": args.iters, "mode": args.mode, "results": results}))
+
+
+if __name__ == "__main__":
+    main()
