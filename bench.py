@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--mode", default="hogwild", choices=["hogwild", "serial", "ordered"])
     ap.add_argument("--sync-every", type=int, default=0, help="steps between item-factor all-reduces (0 = one epoch)")
     ap.add_argument("--merge", default="mean", choices=["mean", "sum", "weighted"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank holds its own full-size user population (default); strong: ONE dataset, "
+                         "users sharded across the ranks (BASELINE.json configs[3])")
     ap.add_argument("--seed", type=int, default=20240917)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-samples", type=int, default=200)
@@ -195,14 +198,19 @@ def main():
     log("dataset ready: %d users, %d items, %d train ratings" % (train.rows, train.cols, train.nnz))
     f = args.factors
     hyper = (0.01, 0.02, 0.02, 0.02, 0.02)  # preprocessing/create_config.py:25-32
+    sync_every = args.sync_every or max(1, int(round(train.nnz / max(int(np.count_nonzero(np.diff(train.indptr))), 1))))
+    user_offset = rank * train.rows  # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the population
+    if args.scaling == "strong" and world > 1:
+        from cu2rec_amd.parallel import plan_users
+        bounds = plan_users(train.rows, world)
+        user_offset = bounds[rank]
+        train, test = train.slice_users(bounds[rank], bounds[rank + 1]), test.slice_users(bounds[rank], bounds[rank + 1])
     users_active = int(np.count_nonzero(np.diff(train.indptr)))
-    sync_every = args.sync_every or max(1, int(round(train.nnz / max(users_active, 1))))
 
     eng = Engine(train.rows, train.cols, f, train.global_bias, device=device)
     d_train, d_test = DeviceRatings(train, device), DeviceRatings(test, device)
-    # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the global population
     rates = cu.api.item_update_rates(train) if args.merge == "weighted" else None
-    job = ShardedSGD(eng, d_train, user_offset=rank * train.rows, sync_every=sync_every, merge=args.merge, item_rates=rates)
+    job = ShardedSGD(eng, d_train, user_offset=user_offset, sync_every=sync_every, merge=args.merge, item_rates=rates)
     if args.iters_per_launch > 1:
         cu.lib().cu2rec_hogwild_iters_per_launch(args.iters_per_launch)
     mode = {"hogwild": cu.SGD_HOGWILD, "serial": cu.SGD_SERIAL, "ordered": cu.SGD_ORDERED}[args.mode]
@@ -235,7 +243,7 @@ def main():
     k_launch = max(args.iters_per_launch, 1) if args.mode == "hogwild" else 1  # iterations covered by one launch
     for a, b in evs:
         a.record()
-        eng.sgd(d_train, hyper, 42, it, k_launch, mode, True, rank * train.rows)
+        eng.sgd(d_train, hyper, 42, it, k_launch, mode, True, user_offset)
         b.record()
         it += k_launch
     torch.cuda.synchronize()
@@ -300,13 +308,18 @@ def main():
     bytes_per_update = 16 * f + 32
     alg_bytes = users_active * bytes_per_update * k_launch
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    value = world * users_active * args.steps / elapsed
+    total_users = users_active * world
+    if world > 1:
+        tu = torch.tensor([float(users_active)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tu)
+        total_users = float(tu.item())
+    value = total_users * args.steps / elapsed
 
     if rank == 0:
         line = {
             "metric": "sgd_updates_per_sec", "value": value, "unit": "updates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s-shape synthetic ratings (users %d, items %d, train nnz %d, test nnz %d per GPU), "
                                    "f=%d, lr .01, reg .02, mode %s%s" % (args.workload, train.rows, train.cols, train.nnz, test.nnz, f,
                                                                            args.mode, "" if args.iters_per_launch == 1 else
