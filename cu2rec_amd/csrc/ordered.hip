@@ -152,6 +152,9 @@ __device__ __forceinline__ void run_rows(RowTile<J, T> &tile, const SgdArgs &a, 
 #ifndef CU2REC_ABLATE
 #define CU2REC_ABLATE 0
 #endif
+#ifndef CU2REC_HOT_DUO
+#define CU2REC_HOT_DUO 1  // J == 2 hot chains: compute wave + memory wave through LDS (0: one half-wave does it all)
+#endif
 constexpr int kWide = 32;
 
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
@@ -278,6 +281,101 @@ __device__ __forceinline__ void run_hot_chain_wide(const SgdArgs &a, const uint6
     if (lane32 == 0) a.item_bias[y] = ib;
 }
 
+// ---- hot chains, two-wave form (J == 2): a compute wave and a memory wave per pair of chains -------------------
+// The chain is latency bound: per update a ~17-deep dependent chain (slot dot, cross-row add, butterfly, error,
+// item-row update).  Everything that is NOT on that chain -- fetching the next users' rows, updating and storing
+// the user's row, the user bias -- is moved to a second wavefront of the same workgroup, which talks to the first
+// one through LDS, double buffered per tile of 8 updates, with ONE __syncthreads() per tile as the only
+// synchronisation (no flags, no spinning: every wave of the block executes the same number of barriers).
+//   wave 0/1 ("A"): chains (0,1)/(2,3) of the block, one per half-wave: reads the tile's user rows / ratings / biases
+//                   from LDS, computes the error, publishes the item row as it was BEFORE the update and the error,
+//                   updates the item row and bias in registers.
+//   wave 2/3 ("B"): same chains: loads tile k+2's rows from global memory (entries three tiles ahead), applies tile
+//                   k-1's user-row and user-bias updates from what A published and stores them, publishes tile k+1.
+constexpr int kDuoChains = 4;
+constexpr int kDuoTile = 8;
+
+struct DuoLds {
+    float4 p[2][kDuoTile][kWide];     // user rows of the tile, as loaded
+    float4 qold[2][kDuoTile][kWide];  // item row before each update of the tile (written by A)
+    float rating[2][kDuoTile], ub[2][kDuoTile], err[2][kDuoTile];
+    int user[2][kDuoTile];
+};
+
+struct DuoTileRegs {
+    float4 rows[kDuoTile];
+    uint64_t val;  // lanes 0..7: entry (user << 32 | rating bits)
+    float ub;      // lanes 0..7: user bias
+};
+
+__device__ __forceinline__ uint64_t duo_load_vals(const uint64_t *__restrict__ vals, int s, int end, int lane32) {
+    return vals[min(s + (lane32 & (kDuoTile - 1)), end - 1)];  // past the chain: a re-read of its last entry, never used
+}
+
+__device__ __forceinline__ void duo_load_rows(DuoTileRegs &r, const SgdArgs &a, uint64_t val, int lane32) {
+    r.val = val;
+    const int my_user = static_cast<int>(val >> 32);
+    r.ub = a.user_bias[my_user];
+#pragma unroll
+    for (int t = 0; t < kDuoTile; ++t) {
+        const int x = __shfl(my_user, t, kWide);
+        r.rows[t] = load_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32);
+    }
+}
+
+__device__ __forceinline__ void duo_publish(DuoLds &l, int buf, const DuoTileRegs &r, int lane32) {
+#pragma unroll
+    for (int t = 0; t < kDuoTile; ++t) l.p[buf][t][lane32] = r.rows[t];
+    if (lane32 < kDuoTile) {
+        l.rating[buf][lane32] = __uint_as_float(static_cast<uint32_t>(r.val));
+        l.ub[buf][lane32] = r.ub;
+        l.user[buf][lane32] = static_cast<int>(r.val >> 32);
+    }
+}
+
+// B: the user side of a finished tile (mf_sequential.cu:133-135,140 with the item row as it was at that update)
+__device__ __forceinline__ void duo_update_users(DuoLds &l, int buf, int n_valid, const SgdArgs &a, int lane32) {
+#pragma unroll
+    for (int t = 0; t < kDuoTile; ++t) {
+        if (t < n_valid) {
+            const float4 po = l.p[buf][t][lane32], qo = l.qold[buf][t][lane32];
+            const float err = l.err[buf][t];
+            float4 pn;
+            pn.x = step(po.x, qo.x, err, a.h.lr, a.h.p_reg);
+            pn.y = step(po.y, qo.y, err, a.h.lr, a.h.p_reg);
+            pn.z = step(po.z, qo.z, err, a.h.lr, a.h.p_reg);
+            pn.w = step(po.w, qo.w, err, a.h.lr, a.h.p_reg);
+            store_wide(a.P, static_cast<size_t>(l.user[buf][t]), a.ldp, a.nslots, lane32, pn);
+        }
+    }
+    if (lane32 < n_valid) {
+        const float ub = l.ub[buf][lane32], err = l.err[buf][lane32];
+        a.user_bias[l.user[buf][lane32]] = ub + a.h.lr * (err - a.h.ub_reg * ub);
+    }
+}
+
+// A: the dependent chain of a tile (same operations, same order as chain_step_wide)
+__device__ __forceinline__ void duo_compute(DuoLds &l, int buf, int n_valid, const SgdArgs &a, float4 &q, float &ib,
+                                            int lane32) {
+#pragma unroll
+    for (int t = 0; t < kDuoTile; ++t) {
+        if (t < n_valid) {
+            const float4 po = l.p[buf][t][lane32];
+            const float rating = l.rating[buf][t], ub = l.ub[buf][t];
+            const float dot = row_sum16(cross_row_sum(slot_dot(q, po)));
+            const float err = rating - (((a.global_bias + ub) + ib) + dot);
+            l.qold[buf][t][lane32] = q;
+            if (lane32 == 0) l.err[buf][t] = err;
+            const float4 qo = q;
+            q.x = step(qo.x, po.x, err, a.h.lr, a.h.q_reg);
+            q.y = step(qo.y, po.y, err, a.h.lr, a.h.q_reg);
+            q.z = step(qo.z, po.z, err, a.h.lr, a.h.q_reg);
+            q.w = step(qo.w, po.w, err, a.h.lr, a.h.q_reg);
+            ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
+        }
+    }
+}
+
 // first position in keys[0, n) whose key is >= target
 __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys, int n, uint32_t target) {
     int lo = 0, hi = n;
@@ -286,6 +384,80 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
         if (keys[mid] < target) lo = mid + 1; else hi = mid;
     }
     return lo;
+}
+
+// One hot block of the J == 2 kernel: four chains, two compute waves, two memory waves (see above).
+__device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32_t *__restrict__ keys,
+                                                  const uint64_t *__restrict__ vals, int n_active, uint32_t key_base,
+                                                  int n_hot, const int *__restrict__ item_of_rank) {
+    __shared__ DuoLds lds[kDuoChains];
+    __shared__ int s_range[kDuoChains][2];
+    const int wave = threadIdx.x >> 6, lane32 = threadIdx.x & (kWide - 1);
+    const bool role_b = wave >= 2;
+    const int c = (wave & 1) * 2 + ((threadIdx.x >> 5) & 1);
+    const int r = blockIdx.x * kDuoChains + c;
+    if (!role_b) {
+        int begin = 0, end = 0;
+        if (r < n_hot) {
+            begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
+            end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));
+        }
+        if (lane32 == 0) {
+            s_range[c][0] = begin;
+            s_range[c][1] = end;
+        }
+    }
+    __syncthreads();
+    const int begin = s_range[c][0], end = s_range[c][1], len = end - begin;
+    int longest = 0;
+#pragma unroll
+    for (int i = 0; i < kDuoChains; ++i) longest = max(longest, s_range[i][1] - s_range[i][0]);
+    const int n_tiles = (longest + kDuoTile - 1) / kDuoTile;  // block uniform: every wave runs the same barriers
+    if (n_tiles == 0) return;
+    const bool alive = len > 0;
+    DuoLds &l = lds[c];
+    const int y = alive ? item_of_rank[r] : 0;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ib = 0.f;
+    DuoTileRegs ready, loading;
+    uint64_t v_next = 0;  // entries of the tile after `ready`
+    if (role_b) {
+        if (alive) {
+            const uint64_t v0 = duo_load_vals(vals, begin, end, lane32);
+            const uint64_t v1 = duo_load_vals(vals, begin + kDuoTile, end, lane32);
+            v_next = duo_load_vals(vals, begin + 2 * kDuoTile, end, lane32);
+            duo_load_rows(loading, a, v0, lane32);
+            duo_load_rows(ready, a, v1, lane32);
+            duo_publish(l, 0, loading, lane32);
+        }
+    } else if (alive) {
+        q = load_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32);
+        ib = a.item_bias[y];
+    }
+    __syncthreads();
+    for (int k = 0; k < n_tiles; ++k) {
+        if (alive) {
+            if (role_b) {
+                const uint64_t v_after = duo_load_vals(vals, begin + (k + 3) * kDuoTile, end, lane32);
+                duo_load_rows(loading, a, v_next, lane32);  // tile k + 2
+                if (k >= 1) duo_update_users(l, (k - 1) & 1, min(max(len - (k - 1) * kDuoTile, 0), kDuoTile), a, lane32);
+                duo_publish(l, (k + 1) & 1, ready, lane32);  // tile k + 1, after the reads of that buffer just above
+                ready = loading;
+                v_next = v_after;
+            } else {
+                duo_compute(l, k & 1, min(max(len - k * kDuoTile, 0), kDuoTile), a, q, ib, lane32);
+            }
+        }
+        __syncthreads();
+    }
+    if (alive) {
+        if (role_b) {
+            duo_update_users(l, (n_tiles - 1) & 1, min(max(len - (n_tiles - 1) * kDuoTile, 0), kDuoTile), a, lane32);
+        } else {
+            store_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32, q);
+            if (lane32 == 0) a.item_bias[y] = ib;
+        }
+    }
 }
 
 template <int J>
@@ -308,12 +480,16 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
     const int lane = threadIdx.x & (kGroup - 1);
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
         if constexpr (J == 2) {
-            // wide layout: half a wavefront per chain
+#if CU2REC_HOT_DUO
+            run_hot_block_duo(a, keys, vals, n_active, key_base, n_hot, item_of_rank);
+#else
+            // single-wave wide layout: half a wavefront per chain does everything
             const int r = (blockIdx.x * kBlock + threadIdx.x) / kWide;
             if (r >= n_hot) return;
             const int begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
             const int end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));
             if (begin < end) run_hot_chain_wide(a, vals, begin, end, item_of_rank[r], threadIdx.x & (kWide - 1));
+#endif
             return;
         }
         constexpr int T = HotTile<J>::value;
@@ -408,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream) {
-    const int chains_per_block = J == 2 ? kBlock / kWide : kGroupsPerBlock;  // J == 2 uses the wide layout
+    const int chains_per_block = J == 2 ? (CU2REC_HOT_DUO ? kDuoChains : kBlock / kWide) : kGroupsPerBlock;
     const int hot_blocks = (n_hot + chains_per_block - 1) / chains_per_block;
     const int groups = (n_active + kWindow - 1) / kWindow;
     const int blocks = hot_blocks + (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
