@@ -419,36 +419,44 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     const int y = alive ? item_of_rank[r] : 0;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float ib = 0.f;
-    DuoTileRegs ready, loading;
-    uint64_t v_next = 0;  // entries of the tile after `ready`
+    // B keeps two register tiles and alternates their roles each phase (no copies: a copy would wait for the
+    // loads that were just issued): at the start of phase k, `r0`/`r1` (by parity of k) holds tile k+1 -- its loads
+    // were issued a whole phase ago -- and the other one receives tile k+2.
+    DuoTileRegs r0, r1;
+    uint64_t v_next = 0;  // entries of tile k+2 at the start of phase k
     if (role_b) {
         if (alive) {
             const uint64_t v0 = duo_load_vals(vals, begin, end, lane32);
             const uint64_t v1 = duo_load_vals(vals, begin + kDuoTile, end, lane32);
             v_next = duo_load_vals(vals, begin + 2 * kDuoTile, end, lane32);
-            duo_load_rows(loading, a, v0, lane32);
-            duo_load_rows(ready, a, v1, lane32);
-            duo_publish(l, 0, loading, lane32);
+            duo_load_rows(r1, a, v0, lane32);
+            duo_load_rows(r0, a, v1, lane32);
+            duo_publish(l, 0, r1, lane32);
         }
     } else if (alive) {
         q = load_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32);
         ib = a.item_bias[y];
     }
     __syncthreads();
-    for (int k = 0; k < n_tiles; ++k) {
+    auto b_phase = [&](int k, DuoTileRegs &ready, DuoTileRegs &loading) {
+        const uint64_t v_after = duo_load_vals(vals, begin + (k + 3) * kDuoTile, end, lane32);
+        duo_load_rows(loading, a, v_next, lane32);  // tile k + 2
+        if (k >= 1) duo_update_users(l, (k - 1) & 1, min(max(len - (k - 1) * kDuoTile, 0), kDuoTile), a, lane32);
+        duo_publish(l, (k + 1) & 1, ready, lane32);  // tile k + 1, after the reads of that buffer just above
+        v_next = v_after;
+    };
+    auto a_phase = [&](int k) { duo_compute(l, k & 1, min(max(len - k * kDuoTile, 0), kDuoTile), a, q, ib, lane32); };
+    for (int k = 0; k < n_tiles; k += 2) {
         if (alive) {
-            if (role_b) {
-                const uint64_t v_after = duo_load_vals(vals, begin + (k + 3) * kDuoTile, end, lane32);
-                duo_load_rows(loading, a, v_next, lane32);  // tile k + 2
-                if (k >= 1) duo_update_users(l, (k - 1) & 1, min(max(len - (k - 1) * kDuoTile, 0), kDuoTile), a, lane32);
-                duo_publish(l, (k + 1) & 1, ready, lane32);  // tile k + 1, after the reads of that buffer just above
-                ready = loading;
-                v_next = v_after;
-            } else {
-                duo_compute(l, k & 1, min(max(len - k * kDuoTile, 0), kDuoTile), a, q, ib, lane32);
-            }
+            if (role_b) b_phase(k, r0, r1); else a_phase(k);
         }
         __syncthreads();
+        if (k + 1 < n_tiles) {  // block uniform
+            if (alive) {
+                if (role_b) b_phase(k + 1, r1, r0); else a_phase(k + 1);
+            }
+            __syncthreads();
+        }
     }
     if (alive) {
         if (role_b) {
