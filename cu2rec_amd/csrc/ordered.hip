@@ -354,25 +354,41 @@ __device__ __forceinline__ void duo_update_users(DuoLds &l, int buf, int n_valid
     }
 }
 
-// A: the dependent chain of a tile (same operations, same order as chain_step_wide)
+// A: the dependent chain of one update (same operations, same order as chain_step_wide); the user's row, rating
+// and bias arrive in registers.
+__device__ __forceinline__ void duo_step_a(DuoLds &l, int buf, int t, const float4 &po, float rating, float ub,
+                                           const SgdArgs &a, float4 &q, float &ib, int lane32) {
+    const float dot = row_sum16(cross_row_sum(slot_dot(q, po)));
+    const float err = rating - (((a.global_bias + ub) + ib) + dot);
+    l.qold[buf][t][lane32] = q;
+    if (lane32 == 0) l.err[buf][t] = err;
+    const float4 qo = q;
+    q.x = step(qo.x, po.x, err, a.h.lr, a.h.q_reg);
+    q.y = step(qo.y, po.y, err, a.h.lr, a.h.q_reg);
+    q.z = step(qo.z, po.z, err, a.h.lr, a.h.q_reg);
+    q.w = step(qo.w, po.w, err, a.h.lr, a.h.q_reg);
+    ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
+}
+
 __device__ __forceinline__ void duo_compute(DuoLds &l, int buf, int n_valid, const SgdArgs &a, float4 &q, float &ib,
                                             int lane32) {
+    if (n_valid == kDuoTile) {
+        // full tile: fetch everything the 8 updates need from LDS up front (one latency per tile, not per update);
+        // the scheduling barrier keeps the compiler from sinking the reads back next to their uses
+        float4 po[kDuoTile];
+        float rating[kDuoTile], ub[kDuoTile];
 #pragma unroll
-    for (int t = 0; t < kDuoTile; ++t) {
-        if (t < n_valid) {
-            const float4 po = l.p[buf][t][lane32];
-            const float rating = l.rating[buf][t], ub = l.ub[buf][t];
-            const float dot = row_sum16(cross_row_sum(slot_dot(q, po)));
-            const float err = rating - (((a.global_bias + ub) + ib) + dot);
-            l.qold[buf][t][lane32] = q;
-            if (lane32 == 0) l.err[buf][t] = err;
-            const float4 qo = q;
-            q.x = step(qo.x, po.x, err, a.h.lr, a.h.q_reg);
-            q.y = step(qo.y, po.y, err, a.h.lr, a.h.q_reg);
-            q.z = step(qo.z, po.z, err, a.h.lr, a.h.q_reg);
-            q.w = step(qo.w, po.w, err, a.h.lr, a.h.q_reg);
-            ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
+        for (int t = 0; t < kDuoTile; ++t) {
+            po[t] = l.p[buf][t][lane32];
+            rating[t] = l.rating[buf][t];
+            ub[t] = l.ub[buf][t];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < kDuoTile; ++t) duo_step_a(l, buf, t, po[t], rating[t], ub[t], a, q, ib, lane32);
+    } else {
+        for (int t = 0; t < n_valid; ++t)
+            duo_step_a(l, buf, t, l.p[buf][t][lane32], l.rating[buf][t], l.ub[buf][t], a, q, ib, lane32);
     }
 }
 
