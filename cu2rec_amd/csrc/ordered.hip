@@ -287,13 +287,15 @@ __device__ __forceinline__ void run_hot_chain_wide(const SgdArgs &a, const uint6
 // the user's row, the user bias -- is moved to a second wavefront of the same workgroup, which talks to the first
 // one through LDS, double buffered per tile of 8 updates, with ONE __syncthreads() per tile as the only
 // synchronisation (no flags, no spinning: every wave of the block executes the same number of barriers).
-//   wave 0/1 ("A"): chains (0,1)/(2,3) of the block, one per half-wave: reads the tile's user rows / ratings / biases
-//                   from LDS, computes the error, publishes the item row as it was BEFORE the update and the error,
-//                   updates the item row and bias in registers.
-//   wave 2/3 ("B"): same chains: loads tile k+2's rows from global memory (entries three tiles ahead), applies tile
-//                   k-1's user-row and user-bias updates from what A published and stores them, publishes tile k+1.
-constexpr int kDuoChains = 4;
-constexpr int kDuoTile = 8;
+//   wave 0 ("A"):      the block's two chains, one per half-wave: reads the tile's user rows / ratings / biases from
+//                      LDS, computes the error, publishes the item row as it was BEFORE the update and the error,
+//                      updates the item row and bias in registers.
+//   waves 1, 2 ("B"):  the same two chains, each wave half of every tile: load tile k+2's rows from global memory
+//                      (entries three tiles ahead), apply tile k-1's user-row and user-bias updates from what A
+//                      published and store them, publish tile k+1.
+constexpr int kDuoChains = 2;  // chains per hot block: wave 0 computes both (one per half-wave), waves 1 and 2 move memory
+constexpr int kDuoTile = 8;    // updates per tile (one barrier per tile)
+constexpr int kDuoPart = 4;    // entries of a tile handled by each of the two memory waves
 
 struct DuoLds {
     float4 p[2][kDuoTile][kWide];     // user rows of the tile, as loaded
@@ -302,14 +304,16 @@ struct DuoLds {
     int user[2][kDuoTile];
 };
 
-struct DuoTileRegs {
-    float4 rows[kDuoTile];
-    uint64_t val;  // lanes 0..7: entry (user << 32 | rating bits)
-    float ub;      // lanes 0..7: user bias
+struct DuoTileRegs {  // one memory wave's share of a tile
+    float4 rows[kDuoPart];
+    uint64_t val;  // lanes 0..3: entry (user << 32 | rating bits)
+    float ub;      // lanes 0..3: user bias
 };
 
-__device__ __forceinline__ uint64_t duo_load_vals(const uint64_t *__restrict__ vals, int s, int end, int lane32) {
-    return vals[min(s + (lane32 & (kDuoTile - 1)), end - 1)];  // past the chain: a re-read of its last entry, never used
+// entries [tile_start + 4 * part, +4) of the chain, one per lane 0..3 (mirrored on the other lanes)
+__device__ __forceinline__ uint64_t duo_load_vals(const uint64_t *__restrict__ vals, int tile_start, int end, int part,
+                                                  int lane32) {
+    return vals[min(tile_start + kDuoPart * part + (lane32 & (kDuoPart - 1)), end - 1)];  // past the chain: its last entry, never used
 }
 
 __device__ __forceinline__ void duo_load_rows(DuoTileRegs &r, const SgdArgs &a, uint64_t val, int lane32) {
@@ -317,40 +321,44 @@ __device__ __forceinline__ void duo_load_rows(DuoTileRegs &r, const SgdArgs &a, 
     const int my_user = static_cast<int>(val >> 32);
     r.ub = a.user_bias[my_user];
 #pragma unroll
-    for (int t = 0; t < kDuoTile; ++t) {
+    for (int t = 0; t < kDuoPart; ++t) {
         const int x = __shfl(my_user, t, kWide);
         r.rows[t] = load_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32);
     }
 }
 
-__device__ __forceinline__ void duo_publish(DuoLds &l, int buf, const DuoTileRegs &r, int lane32) {
+__device__ __forceinline__ void duo_publish(DuoLds &l, int buf, const DuoTileRegs &r, int part, int lane32) {
 #pragma unroll
-    for (int t = 0; t < kDuoTile; ++t) l.p[buf][t][lane32] = r.rows[t];
-    if (lane32 < kDuoTile) {
-        l.rating[buf][lane32] = __uint_as_float(static_cast<uint32_t>(r.val));
-        l.ub[buf][lane32] = r.ub;
-        l.user[buf][lane32] = static_cast<int>(r.val >> 32);
+    for (int t = 0; t < kDuoPart; ++t) l.p[buf][kDuoPart * part + t][lane32] = r.rows[t];
+    if (lane32 < kDuoPart) {
+        const int e = kDuoPart * part + lane32;
+        l.rating[buf][e] = __uint_as_float(static_cast<uint32_t>(r.val));
+        l.ub[buf][e] = r.ub;
+        l.user[buf][e] = static_cast<int>(r.val >> 32);
     }
 }
 
-// B: the user side of a finished tile (mf_sequential.cu:133-135,140 with the item row as it was at that update)
-__device__ __forceinline__ void duo_update_users(DuoLds &l, int buf, int n_valid, const SgdArgs &a, int lane32) {
+// B: the user side of this wave's share of a finished tile (mf_sequential.cu:133-135,140 with the item row as it
+// was at that update)
+__device__ __forceinline__ void duo_update_users(DuoLds &l, int buf, int n_valid, const SgdArgs &a, int part, int lane32) {
 #pragma unroll
-    for (int t = 0; t < kDuoTile; ++t) {
-        if (t < n_valid) {
-            const float4 po = l.p[buf][t][lane32], qo = l.qold[buf][t][lane32];
-            const float err = l.err[buf][t];
+    for (int t = 0; t < kDuoPart; ++t) {
+        const int e = kDuoPart * part + t;
+        if (e < n_valid) {
+            const float4 po = l.p[buf][e][lane32], qo = l.qold[buf][e][lane32];
+            const float err = l.err[buf][e];
             float4 pn;
             pn.x = step(po.x, qo.x, err, a.h.lr, a.h.p_reg);
             pn.y = step(po.y, qo.y, err, a.h.lr, a.h.p_reg);
             pn.z = step(po.z, qo.z, err, a.h.lr, a.h.p_reg);
             pn.w = step(po.w, qo.w, err, a.h.lr, a.h.p_reg);
-            store_wide(a.P, static_cast<size_t>(l.user[buf][t]), a.ldp, a.nslots, lane32, pn);
+            store_wide(a.P, static_cast<size_t>(l.user[buf][e]), a.ldp, a.nslots, lane32, pn);
         }
     }
-    if (lane32 < n_valid) {
-        const float ub = l.ub[buf][lane32], err = l.err[buf][lane32];
-        a.user_bias[l.user[buf][lane32]] = ub + a.h.lr * (err - a.h.ub_reg * ub);
+    const int mine = kDuoPart * part + lane32;
+    if (lane32 < kDuoPart && mine < n_valid) {
+        const float ub = l.ub[buf][mine], err = l.err[buf][mine];
+        a.user_bias[l.user[buf][mine]] = ub + a.h.lr * (err - a.h.ub_reg * ub);
     }
 }
 
@@ -360,8 +368,10 @@ __device__ __forceinline__ void duo_step_a(DuoLds &l, int buf, int t, const floa
                                            const SgdArgs &a, float4 &q, float &ib, int lane32) {
     const float dot = row_sum16(cross_row_sum(slot_dot(q, po)));
     const float err = rating - (((a.global_bias + ub) + ib) + dot);
+#if !(CU2REC_ABLATE & 16)
     l.qold[buf][t][lane32] = q;
     if (lane32 == 0) l.err[buf][t] = err;
+#endif
     const float4 qo = q;
     q.x = step(qo.x, po.x, err, a.h.lr, a.h.q_reg);
     q.y = step(qo.y, po.y, err, a.h.lr, a.h.q_reg);
@@ -402,17 +412,19 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
     return lo;
 }
 
-// One hot block of the J == 2 kernel: four chains, two compute waves, two memory waves (see above).
+// One hot block of the J == 2 kernel: two chains; wave 0 computes (one chain per half-wave), waves 1 and 2 each move
+// half of every tile's memory traffic, wave 3 only keeps the barriers company.
 __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32_t *__restrict__ keys,
                                                   const uint64_t *__restrict__ vals, int n_active, uint32_t key_base,
                                                   int n_hot, const int *__restrict__ item_of_rank) {
     __shared__ DuoLds lds[kDuoChains];
     __shared__ int s_range[kDuoChains][2];
     const int wave = threadIdx.x >> 6, lane32 = threadIdx.x & (kWide - 1);
-    const bool role_b = wave >= 2;
-    const int c = (wave & 1) * 2 + ((threadIdx.x >> 5) & 1);
+    const bool role_a = wave == 0, role_b = wave == 1 || wave == 2;
+    const int part = wave - 1;                // memory waves: which half of the tile
+    const int c = (threadIdx.x >> 5) & 1;     // chain of this half-wave
     const int r = blockIdx.x * kDuoChains + c;
-    if (!role_b) {
+    if (role_a) {
         int begin = 0, end = 0;
         if (r < n_hot) {
             begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
@@ -425,40 +437,40 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     }
     __syncthreads();
     const int begin = s_range[c][0], end = s_range[c][1], len = end - begin;
-    int longest = 0;
-#pragma unroll
-    for (int i = 0; i < kDuoChains; ++i) longest = max(longest, s_range[i][1] - s_range[i][0]);
+    const int longest = max(s_range[0][1] - s_range[0][0], s_range[1][1] - s_range[1][0]);
     const int n_tiles = (longest + kDuoTile - 1) / kDuoTile;  // block uniform: every wave runs the same barriers
     if (n_tiles == 0) return;
-    const bool alive = len > 0;
+    const bool alive = len > 0 && (role_a || role_b);
     DuoLds &l = lds[c];
     const int y = alive ? item_of_rank[r] : 0;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float ib = 0.f;
-    // B keeps two register tiles and alternates their roles each phase (no copies: a copy would wait for the
-    // loads that were just issued): at the start of phase k, `r0`/`r1` (by parity of k) holds tile k+1 -- its loads
-    // were issued a whole phase ago -- and the other one receives tile k+2.
+    // A memory wave keeps two register tiles and alternates their roles each phase (no copies: a copy would wait for
+    // the loads just issued): at the start of phase k, r0 / r1 (by parity of k) holds its share of tile k+1 -- loads
+    // issued a whole phase ago -- and the other one receives tile k+2.
     DuoTileRegs r0, r1;
-    uint64_t v_next = 0;  // entries of tile k+2 at the start of phase k
-    if (role_b) {
-        if (alive) {
-            const uint64_t v0 = duo_load_vals(vals, begin, end, lane32);
-            const uint64_t v1 = duo_load_vals(vals, begin + kDuoTile, end, lane32);
-            v_next = duo_load_vals(vals, begin + 2 * kDuoTile, end, lane32);
-            duo_load_rows(r1, a, v0, lane32);
-            duo_load_rows(r0, a, v1, lane32);
-            duo_publish(l, 0, r1, lane32);
-        }
+    uint64_t v_next = 0;  // this wave's entries of tile k+2 at the start of phase k
+    if (alive && role_b) {
+        const uint64_t v0 = duo_load_vals(vals, begin, end, part, lane32);
+        const uint64_t v1 = duo_load_vals(vals, begin + kDuoTile, end, part, lane32);
+        v_next = duo_load_vals(vals, begin + 2 * kDuoTile, end, part, lane32);
+        duo_load_rows(r1, a, v0, lane32);
+        duo_load_rows(r0, a, v1, lane32);
+        duo_publish(l, 0, r1, part, lane32);
     } else if (alive) {
         q = load_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32);
         ib = a.item_bias[y];
     }
     __syncthreads();
     auto b_phase = [&](int k, DuoTileRegs &ready, DuoTileRegs &loading) {
-        const uint64_t v_after = duo_load_vals(vals, begin + (k + 3) * kDuoTile, end, lane32);
+        const uint64_t v_after = duo_load_vals(vals, begin + (k + 3) * kDuoTile, end, part, lane32);
+#if !(CU2REC_ABLATE & 32)
         duo_load_rows(loading, a, v_next, lane32);  // tile k + 2
-        if (k >= 1) duo_update_users(l, (k - 1) & 1, min(max(len - (k - 1) * kDuoTile, 0), kDuoTile), a, lane32);
-        duo_publish(l, (k + 1) & 1, ready, lane32);  // tile k + 1, after the reads of that buffer just above
+#endif
+#if !(CU2REC_ABLATE & 8)
+        if (k >= 1) duo_update_users(l, (k - 1) & 1, min(max(len - (k - 1) * kDuoTile, 0), kDuoTile), a, part, lane32);
+#endif
+        duo_publish(l, (k + 1) & 1, ready, part, lane32);  // tile k + 1, after the reads of that buffer just above
         v_next = v_after;
     };
     auto a_phase = [&](int k) { duo_compute(l, k & 1, min(max(len - k * kDuoTile, 0), kDuoTile), a, q, ib, lane32); };
@@ -476,7 +488,7 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     }
     if (alive) {
         if (role_b) {
-            duo_update_users(l, (n_tiles - 1) & 1, min(max(len - (n_tiles - 1) * kDuoTile, 0), kDuoTile), a, lane32);
+            duo_update_users(l, (n_tiles - 1) & 1, min(max(len - (n_tiles - 1) * kDuoTile, 0), kDuoTile), a, part, lane32);
         } else {
             store_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32, q);
             if (lane32 == 0) a.item_bias[y] = ib;
