@@ -517,3 +517,31 @@ def test_train_sharded_world1_equals_cpp_train(tmp_path):
     assert "TEST: Iteration 24 GPU MAE:" in out
     for comp in ("p", "q", "user_bias", "item_bias", "global_bias"):
         assert (d1 / ("train_f12_%s.csv" % comp)).read_text() == (d2 / ("train_f12_%s.csv" % comp)).read_text(), comp
+
+
+def test_converged_run_matches_mf_sequential_within_1e4():
+    """North-star criterion on BASELINE.json configs[1] (ML-1M shape, f=50): a full train() run -- 2,000 iterations,
+    loss every 500, patience / LR decay -- in ordered mode against (a) the oracle in the kernels' summation order:
+    every parameter and every logged loss bit for bit, and (b) the oracle in the reference's own order
+    (mf_sequential.cu arithmetic, sequential dot product): final test RMSE within 1e-4, parameters within 1e-3."""
+    import bench
+    tr, te = bench.load_dataset("ml-1m", 20240917, 0, lambda: None)
+    f, iters = 50, 2000
+    kw = dict(total_iterations=iters, n_factors=f, check_error=500, learning_rate=0.01)
+    cfg = cu.default_config(**kw)
+    gP, gQ, losses, gub, gib = cu.train(tr, te, cfg, mode="ordered", verbose=False)
+    logs = {}
+    for name, order in (("tree", orc.DOT_TREE16), ("seq", orc.DOT_SEQ)):
+        ocfg = orc.default_config(**kw)
+        P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+        logs[name] = (orc.train(_as_orc(tr), _as_orc(te), ocfg, P, Q, ub, ib, tr.global_bias, dot_order=order,
+                                acc=orc.ACC_F64, schedule=orc.SCHED_PATIENCE), (P, Q, ub, ib), ocfg.learning_rate)
+    log, (P, Q, ub, ib), lr = logs["tree"]
+    np.testing.assert_array_equal(gP, P)
+    np.testing.assert_array_equal(gQ, Q)
+    np.testing.assert_array_equal(gub, ub)
+    np.testing.assert_array_equal(gib, ib)
+    assert [losses[e["iteration"] - 1] for e in log] == [e["test_rmse"] for e in log] and cfg.learning_rate == lr
+    log_s, (Ps, Qs, ubs, ibs), _ = logs["seq"]
+    assert abs(float(losses[iters - 1]) - log_s[-1]["test_rmse"]) <= 1e-4
+    assert np.abs(gP - Ps).max() <= 1e-3 and np.abs(gQ - Qs).max() <= 1e-3
