@@ -153,7 +153,7 @@ __device__ __forceinline__ void run_rows(RowTile<J, T> &tile, const SgdArgs &a, 
 #define CU2REC_ABLATE 0
 #endif
 #ifndef CU2REC_HOT_DUO
-#define CU2REC_HOT_DUO 1  // J == 2 hot chains: compute wave + memory wave through LDS (0: one half-wave does it all)
+#define CU2REC_HOT_DUO 1  // hot chains with ld <= 128: compute wave + memory waves through LDS (0: one lane group does it all)
 #endif
 constexpr int kWide = 32;
 
@@ -293,13 +293,15 @@ __device__ __forceinline__ void run_hot_chain_wide(const SgdArgs &a, const uint6
 //   waves 1, 2 ("B"):  the same two chains, each wave half of every tile: load tile k+2's rows from global memory
 //                      (entries three tiles ahead), apply tile k-1's user-row and user-bias updates from what A
 //                      published and store them, publish tile k+1.
-constexpr int kDuoChains = 2;  // chains per hot block: wave 0 computes both (one per half-wave), waves 1 and 2 move memory
+// W = lanes per chain: 32 (one slot per lane, 65 <= ld <= 128) or 16 (ld <= 64); wave 0 computes 64 / W chains,
+// waves 1 and 2 move their memory
 constexpr int kDuoTile = 8;    // updates per tile (one barrier per tile)
 constexpr int kDuoPart = 4;    // entries of a tile handled by each of the two memory waves
 
+template <int W>
 struct DuoLds {
-    float4 p[2][kDuoTile][kWide];     // user rows of the tile, as loaded
-    float4 qold[2][kDuoTile][kWide];  // item row before each update of the tile (written by A)
+    float4 p[2][kDuoTile][W];     // user rows of the tile, as loaded
+    float4 qold[2][kDuoTile][W];  // item row before each update of the tile (written by A)
     float rating[2][kDuoTile], ub[2][kDuoTile], err[2][kDuoTile];
     int user[2][kDuoTile];
 };
@@ -316,18 +318,20 @@ __device__ __forceinline__ uint64_t duo_load_vals(const uint64_t *__restrict__ v
     return vals[min(tile_start + kDuoPart * part + (lane32 & (kDuoPart - 1)), end - 1)];  // past the chain: its last entry, never used
 }
 
+template <int W>
 __device__ __forceinline__ void duo_load_rows(DuoTileRegs &r, const SgdArgs &a, uint64_t val, int lane32) {
     r.val = val;
     const int my_user = static_cast<int>(val >> 32);
     r.ub = a.user_bias[my_user];
 #pragma unroll
     for (int t = 0; t < kDuoPart; ++t) {
-        const int x = __shfl(my_user, t, kWide);
+        const int x = __shfl(my_user, t, W);
         r.rows[t] = load_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32);
     }
 }
 
-__device__ __forceinline__ void duo_publish(DuoLds &l, int buf, const DuoTileRegs &r, int part, int lane32) {
+template <int W>
+__device__ __forceinline__ void duo_publish(DuoLds<W> &l, int buf, const DuoTileRegs &r, int part, int lane32) {
 #pragma unroll
     for (int t = 0; t < kDuoPart; ++t) l.p[buf][kDuoPart * part + t][lane32] = r.rows[t];
     if (lane32 < kDuoPart) {
@@ -340,7 +344,8 @@ __device__ __forceinline__ void duo_publish(DuoLds &l, int buf, const DuoTileReg
 
 // B: the user side of this wave's share of a finished tile (mf_sequential.cu:133-135,140 with the item row as it
 // was at that update)
-__device__ __forceinline__ void duo_update_users(DuoLds &l, int buf, int n_valid, const SgdArgs &a, int part, int lane32) {
+template <int W>
+__device__ __forceinline__ void duo_update_users(DuoLds<W> &l, int buf, int n_valid, const SgdArgs &a, int part, int lane32) {
 #pragma unroll
     for (int t = 0; t < kDuoPart; ++t) {
         const int e = kDuoPart * part + t;
@@ -364,9 +369,11 @@ __device__ __forceinline__ void duo_update_users(DuoLds &l, int buf, int n_valid
 
 // A: the dependent chain of one update (same operations, same order as chain_step_wide); the user's row, rating
 // and bias arrive in registers.
-__device__ __forceinline__ void duo_step_a(DuoLds &l, int buf, int t, const float4 &po, float rating, float ub,
+template <int W>
+__device__ __forceinline__ void duo_step_a(DuoLds<W> &l, int buf, int t, const float4 &po, float rating, float ub,
                                            const SgdArgs &a, float4 &q, float &ib, int lane32) {
-    const float dot = row_sum16(cross_row_sum(slot_dot(q, po)));
+    const float s = slot_dot(q, po);
+    const float dot = W == kWide ? row_sum16(cross_row_sum(s)) : row_sum16(s);  // canonical order either way
     const float err = rating - (((a.global_bias + ub) + ib) + dot);
 #if !(CU2REC_ABLATE & 16)
     l.qold[buf][t][lane32] = q;
@@ -380,7 +387,8 @@ __device__ __forceinline__ void duo_step_a(DuoLds &l, int buf, int t, const floa
     ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
 }
 
-__device__ __forceinline__ void duo_compute(DuoLds &l, int buf, int n_valid, const SgdArgs &a, float4 &q, float &ib,
+template <int W>
+__device__ __forceinline__ void duo_compute(DuoLds<W> &l, int buf, int n_valid, const SgdArgs &a, float4 &q, float &ib,
                                             int lane32) {
     if (n_valid == kDuoTile) {
         // full tile: fetch everything the 8 updates need from LDS up front (one latency per tile, not per update);
@@ -395,10 +403,10 @@ __device__ __forceinline__ void duo_compute(DuoLds &l, int buf, int n_valid, con
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < kDuoTile; ++t) duo_step_a(l, buf, t, po[t], rating[t], ub[t], a, q, ib, lane32);
+        for (int t = 0; t < kDuoTile; ++t) duo_step_a<W>(l, buf, t, po[t], rating[t], ub[t], a, q, ib, lane32);
     } else {
         for (int t = 0; t < n_valid; ++t)
-            duo_step_a(l, buf, t, l.p[buf][t][lane32], l.rating[buf][t], l.ub[buf][t], a, q, ib, lane32);
+            duo_step_a<W>(l, buf, t, l.p[buf][t][lane32], l.rating[buf][t], l.ub[buf][t], a, q, ib, lane32);
     }
 }
 
@@ -412,18 +420,20 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
     return lo;
 }
 
-// One hot block of the J == 2 kernel: two chains; wave 0 computes (one chain per half-wave), waves 1 and 2 each move
-// half of every tile's memory traffic, wave 3 only keeps the barriers company.
+// One hot block: 64 / W chains; wave 0 computes (W lanes per chain), waves 1 and 2 each move half of every tile's
+// memory traffic, wave 3 only keeps the barriers company.
+template <int W>
 __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32_t *__restrict__ keys,
                                                   const uint64_t *__restrict__ vals, int n_active, uint32_t key_base,
                                                   int n_hot, const int *__restrict__ item_of_rank) {
-    __shared__ DuoLds lds[kDuoChains];
-    __shared__ int s_range[kDuoChains][2];
-    const int wave = threadIdx.x >> 6, lane32 = threadIdx.x & (kWide - 1);
+    constexpr int kChains = 64 / W;
+    __shared__ DuoLds<W> lds[kChains];
+    __shared__ int s_range[kChains][2];
+    const int wave = threadIdx.x >> 6, lane32 = threadIdx.x & (W - 1);
     const bool role_a = wave == 0, role_b = wave == 1 || wave == 2;
     const int part = wave - 1;                // memory waves: which half of the tile
-    const int c = (threadIdx.x >> 5) & 1;     // chain of this half-wave
-    const int r = blockIdx.x * kDuoChains + c;
+    const int c = (threadIdx.x & 63) / W;      // chain of this lane group
+    const int r = blockIdx.x * kChains + c;
     if (role_a) {
         int begin = 0, end = 0;
         if (r < n_hot) {
@@ -437,11 +447,13 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     }
     __syncthreads();
     const int begin = s_range[c][0], end = s_range[c][1], len = end - begin;
-    const int longest = max(s_range[0][1] - s_range[0][0], s_range[1][1] - s_range[1][0]);
+    int longest = 0;
+#pragma unroll
+    for (int i = 0; i < kChains; ++i) longest = max(longest, s_range[i][1] - s_range[i][0]);
     const int n_tiles = (longest + kDuoTile - 1) / kDuoTile;  // block uniform: every wave runs the same barriers
     if (n_tiles == 0) return;
     const bool alive = len > 0 && (role_a || role_b);
-    DuoLds &l = lds[c];
+    DuoLds<W> &l = lds[c];
     const int y = alive ? item_of_rank[r] : 0;
     float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
     float ib = 0.f;
@@ -454,9 +466,9 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
         const uint64_t v0 = duo_load_vals(vals, begin, end, part, lane32);
         const uint64_t v1 = duo_load_vals(vals, begin + kDuoTile, end, part, lane32);
         v_next = duo_load_vals(vals, begin + 2 * kDuoTile, end, part, lane32);
-        duo_load_rows(r1, a, v0, lane32);
-        duo_load_rows(r0, a, v1, lane32);
-        duo_publish(l, 0, r1, part, lane32);
+        duo_load_rows<W>(r1, a, v0, lane32);
+        duo_load_rows<W>(r0, a, v1, lane32);
+        duo_publish<W>(l, 0, r1, part, lane32);
     } else if (alive) {
         q = load_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32);
         ib = a.item_bias[y];
@@ -465,15 +477,15 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     auto b_phase = [&](int k, DuoTileRegs &ready, DuoTileRegs &loading) {
         const uint64_t v_after = duo_load_vals(vals, begin + (k + 3) * kDuoTile, end, part, lane32);
 #if !(CU2REC_ABLATE & 32)
-        duo_load_rows(loading, a, v_next, lane32);  // tile k + 2
+        duo_load_rows<W>(loading, a, v_next, lane32);  // tile k + 2
 #endif
 #if !(CU2REC_ABLATE & 8)
-        if (k >= 1) duo_update_users(l, (k - 1) & 1, min(max(len - (k - 1) * kDuoTile, 0), kDuoTile), a, part, lane32);
+        if (k >= 1) duo_update_users<W>(l, (k - 1) & 1, min(max(len - (k - 1) * kDuoTile, 0), kDuoTile), a, part, lane32);
 #endif
-        duo_publish(l, (k + 1) & 1, ready, part, lane32);  // tile k + 1, after the reads of that buffer just above
+        duo_publish<W>(l, (k + 1) & 1, ready, part, lane32);  // tile k + 1, after the reads of that buffer just above
         v_next = v_after;
     };
-    auto a_phase = [&](int k) { duo_compute(l, k & 1, min(max(len - k * kDuoTile, 0), kDuoTile), a, q, ib, lane32); };
+    auto a_phase = [&](int k) { duo_compute<W>(l, k & 1, min(max(len - k * kDuoTile, 0), kDuoTile), a, q, ib, lane32); };
     for (int k = 0; k < n_tiles; k += 2) {
         if (alive) {
             if (role_b) b_phase(k, r0, r1); else a_phase(k);
@@ -488,7 +500,7 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     }
     if (alive) {
         if (role_b) {
-            duo_update_users(l, (n_tiles - 1) & 1, min(max(len - (n_tiles - 1) * kDuoTile, 0), kDuoTile), a, part, lane32);
+            duo_update_users<W>(l, (n_tiles - 1) & 1, min(max(len - (n_tiles - 1) * kDuoTile, 0), kDuoTile), a, part, lane32);
         } else {
             store_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32, q);
             if (lane32 == 0) a.item_bias[y] = ib;
@@ -515,19 +527,22 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
                                                              int hot_blocks) {
     const int lane = threadIdx.x & (kGroup - 1);
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
-        if constexpr (J == 2) {
 #if CU2REC_HOT_DUO
-            run_hot_block_duo(a, keys, vals, n_active, key_base, n_hot, item_of_rank);
+        if constexpr (J <= 2) {
+            run_hot_block_duo<(J == 2 ? kWide : kGroup)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank);
+            return;
+        }
 #else
+        if constexpr (J == 2) {
             // single-wave wide layout: half a wavefront per chain does everything
             const int r = (blockIdx.x * kBlock + threadIdx.x) / kWide;
             if (r >= n_hot) return;
             const int begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
             const int end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));
             if (begin < end) run_hot_chain_wide(a, vals, begin, end, item_of_rank[r], threadIdx.x & (kWide - 1));
-#endif
             return;
         }
+#endif
         constexpr int T = HotTile<J>::value;
         const int r = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
         if (r >= n_hot) return;
@@ -620,7 +635,8 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream) {
-    const int chains_per_block = J == 2 ? (CU2REC_HOT_DUO ? kDuoChains : kBlock / kWide) : kGroupsPerBlock;
+    // hot blocks: two-wave form for ld <= 128 (64 / W chains per block), one group per chain otherwise
+    const int chains_per_block = CU2REC_HOT_DUO ? (J == 2 ? 2 : (J == 1 ? 4 : kGroupsPerBlock)) : (J == 2 ? kBlock / kWide : kGroupsPerBlock);
     const int hot_blocks = (n_hot + chains_per_block - 1) / chains_per_block;
     const int groups = (n_active + kWindow - 1) / kWindow;
     const int blocks = hot_blocks + (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
