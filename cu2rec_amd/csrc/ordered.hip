@@ -16,9 +16,13 @@
 //      ascending inside a chain).  Afterwards iteration b occupies [b * n_active, (b+1) * n_active), chains are
 //      runs of equal keys, and because keys carry the item's popularity RANK, the longest chains come first.
 //   3. sgd_ordered_kernel, one launch per iteration (the kernel boundary carries the P-row dependency from
-//      iteration b to b+1): a 16-lane group owns a window of 4 sorted positions and runs every chain that
-//      STARTS in its window to its end, with the item row and item bias held in registers for the whole chain
-//      (the item row is read and written once per chain, not once per update).
+//      iteration b to b+1).  The item row and item bias stay in registers for a whole chain (read and written once
+//      per chain, not once per update).  Two block roles:
+//        hot blocks      the chains of the 256 most popular items.  Their length (thousands of dependent updates) IS
+//                        the iteration's critical path, so for ld <= 128 a block splits each chain over wavefronts:
+//                        a compute wave runs only the dependent arithmetic, two memory waves prefetch the users' rows,
+//                        publish them through LDS and apply / store the user-side updates (run_hot_block_duo).
+//        regular blocks  a 16-lane group owns a window of 4 sorted positions and runs every chain that STARTS there.
 // The arithmetic of one update is the same device code as the Hogwild kernel (sgd_device.hpp).
 #include <hip/hip_runtime.h>
 

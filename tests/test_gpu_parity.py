@@ -190,7 +190,24 @@ def test_sgd_hogwild_blocked_launches():
         np.testing.assert_array_equal(g, w)
 
 
-@pytest.mark.parametrize("f", [10, 100])
+def test_factor_range_limits():
+    """n_factors up to 512 is compiled in (J = 8 slots per lane); beyond that the library refuses, loudly."""
+    tr, _ = _small_set(users=60, items=40, nnz=600, seed=13)
+    f = 512
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    d = cu.DeviceCSR(tr)
+    model.sgd(d, HYPER, 42, 0, 3, mode="ordered")
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, 3, dot_order=orc.DOT_TREE16)
+    for g, w in zip(model.download(), (P, Q, ub, ib)):
+        np.testing.assert_array_equal(g, w)
+    assert model.loss(d)["rmse"] == orc.loss(_as_orc(tr), P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_TREE16)["rmse"]
+    with pytest.raises(cu.Cu2recError) as e:
+        cu.Model(tr.rows, tr.cols, 513, tr.global_bias)
+    assert e.value.status == -6  # CU2REC_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("f", [10, 100, 300])
 def test_sgd_hogwild_one_iteration_is_jacobi(f):
     """One Hogwild iteration: every user's P row / bias is the update computed from the item row as it
     was at the start of the launch or as some concurrent update left it; for items sampled by exactly
