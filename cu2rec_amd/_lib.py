@@ -98,6 +98,7 @@ SIGNATURES = {
     "cu2rec_shard_plan": (C.c_int, [C.c_int, C.c_int, _P]),
     "cu2rec_csr_slice": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _ip, _ip]),
     "cu2rec_items_delta_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "cu2rec_items_delta_apply_overlapped": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_float, _P]),
     "cu2rec_items_delta_pack_weighted": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "cu2rec_item_update_rates": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "cu2rec_items_delta_apply": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_float, _P]),

@@ -485,6 +485,19 @@ int cu2rec_items_delta_pack(const float *Q, const float *item_bias, const float 
     });
 }
 
+int cu2rec_items_delta_apply_overlapped(float *Q, float *item_bias, float *Q_base, float *ib_base, const float *Q_snap,
+                                        const float *ib_snap, int n_cols, int ldq, const float *buf, float scale,
+                                        void *stream) {
+    return guarded([&] {
+        require(Q && item_bias && Q_base && ib_base && Q_snap && ib_snap && buf && n_cols >= 0 && ldq > 0, "bad argument");
+        require_device();
+        if (n_cols == 0) return;
+        launch_items_delta_apply_overlapped(Q, item_bias, Q_base, ib_base, Q_snap, ib_snap, n_cols, ldq, buf, scale,
+                                            as_stream(stream));
+        CU2REC_HIP(hipGetLastError());
+    });
+}
+
 int cu2rec_items_delta_pack_weighted(const float *Q, const float *item_bias, const float *Q_base, const float *ib_base,
                                      const float *item_weight, int n_cols, int ldq, float *buf, void *stream) {
     return guarded([&] {

@@ -253,6 +253,26 @@ __global__ __launch_bounds__(kBlock) void items_delta_apply_kernel(float *__rest
     }
 }
 
+__global__ __launch_bounds__(kBlock) void items_delta_apply_overlapped_kernel(
+    float *__restrict__ Q, float *__restrict__ ib, float *__restrict__ Q_base, float *__restrict__ ib_base,
+    const float *__restrict__ Q_snap, const float *__restrict__ ib_snap, size_t nq, int n_cols,
+    const float *__restrict__ buf, float scale) {
+    const size_t total = nq + static_cast<size_t>(n_cols);
+    for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        if (i < nq) {
+            const float merged = Q_base[i] + scale * buf[i];
+            Q[i] = merged + (Q[i] - Q_snap[i]);
+            Q_base[i] = merged;
+        } else {
+            const size_t j = i - nq;
+            const float merged = ib_base[j] + scale * buf[i];
+            ib[j] = merged + (ib[j] - ib_snap[j]);
+            ib_base[j] = merged;
+        }
+    }
+}
+
 inline int blocks_for(size_t work_items, size_t per_block, int cap) {
     size_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -325,6 +345,15 @@ void launch_items_delta_pack(const float *Q, const float *ib, const float *Q_bas
     const int blocks = blocks_for(nq + n_cols, kBlock * 4, 4096);
     hipLaunchKernelGGL(items_delta_pack_kernel, dim3(blocks), dim3(kBlock), 0, stream, Q, ib, Q_base, ib_base, nq,
                        n_cols, buf);
+}
+
+void launch_items_delta_apply_overlapped(float *Q, float *ib, float *Q_base, float *ib_base, const float *Q_snap,
+                                         const float *ib_snap, int n_cols, int ldq, const float *buf, float scale,
+                                         hipStream_t stream) {
+    const size_t nq = static_cast<size_t>(n_cols) * ldq;
+    const int blocks = blocks_for(nq + n_cols, kBlock * 4, 4096);
+    hipLaunchKernelGGL(items_delta_apply_overlapped_kernel, dim3(blocks), dim3(kBlock), 0, stream, Q, ib, Q_base, ib_base,
+                       Q_snap, ib_snap, nq, n_cols, buf, scale);
 }
 
 void launch_items_delta_pack_weighted(const float *Q, const float *ib, const float *Q_base, const float *ib_base,

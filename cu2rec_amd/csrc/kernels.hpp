@@ -61,6 +61,9 @@ int error_metrics_blocks(int n);
 void launch_error_metrics(const float *errors, int n, double *partials, int blocks, hipStream_t stream);
 void launch_items_delta_pack(const float *Q, const float *ib, const float *Q_base, const float *ib_base, int n_cols,
                              int ldq, float *buf, hipStream_t stream);
+void launch_items_delta_apply_overlapped(float *Q, float *ib, float *Q_base, float *ib_base, const float *Q_snap,
+                                         const float *ib_snap, int n_cols, int ldq, const float *buf, float scale,
+                                         hipStream_t stream);
 void launch_items_delta_pack_weighted(const float *Q, const float *ib, const float *Q_base, const float *ib_base,
                                       const float *weight, int n_cols, int ldq, float *buf, hipStream_t stream);
 void launch_items_delta_apply(float *Q, float *ib, float *Q_base, float *ib_base, int n_cols, int ldq,

@@ -125,6 +125,21 @@ class Engine:
                                             self.exchange.data_ptr(), _stream_ptr()))
         return self.exchange
 
+    def snapshot_for_overlap(self):
+        """Remember Q / item_bias as they are now (called right after pack_item_delta, before training continues)."""
+        if getattr(self, "Q_snap", None) is None:
+            self.Q_snap, self.item_bias_snap = torch.empty_like(self.Q), torch.empty_like(self.item_bias)
+        self.Q_snap.copy_(self.Q)
+        self.item_bias_snap.copy_(self.item_bias)
+
+    def apply_item_delta_overlapped(self, scale=1.0):
+        """Q <- (Q_base + scale * exchange) + (Q - Q_snap); Q_base <- Q_base + scale * exchange (same for item_bias)."""
+        from ._lib import check
+        check(lib().cu2rec_items_delta_apply_overlapped(self.Q.data_ptr(), self.item_bias.data_ptr(), self.Q_base.data_ptr(),
+                                                        self.item_bias_base.data_ptr(), self.Q_snap.data_ptr(),
+                                                        self.item_bias_snap.data_ptr(), self.item_bias.numel(), self.ld,
+                                                        self.exchange.data_ptr(), float(scale), _stream_ptr()))
+
     def apply_item_delta(self, scale=1.0):
         """Q <- Q_base + scale * exchange_Q (same for item_bias); the result is the new snapshot."""
         from ._lib import check

@@ -32,7 +32,8 @@ def plan_users(n_users, world_size):
 
 
 class ShardedSGD:
-    def __init__(self, engine, ratings, user_offset=0, sync_every=100, merge="mean", group=None, item_rates=None):
+    def __init__(self, engine, ratings, user_offset=0, sync_every=100, merge="mean", group=None, item_rates=None,
+                 overlap=None):
         """merge: how the replicas' item deltas are combined at an exchange --
              "mean"      delta = (1/N) sum_k delta_k       right when every rank sees every item about equally often
              "sum"       delta = sum_k delta_k             right when every item is updated by (almost) one rank only
@@ -48,6 +49,15 @@ class ShardedSGD:
         self.since_sync = 0
         self.exchanges = 0
         self.item_weight = None
+        # overlap=True: the all-reduce of period t runs while period t+1 trains; its result is folded in at the next
+        # sync point (item deltas arrive one period late, local progress made meanwhile is kept).  Default: on for
+        # RCCL, where the collective runs on its own stream next to the SGD kernels; CU2REC_EXCHANGE_OVERLAP=0/1 overrides.
+        import os
+        if overlap is None:
+            env = os.environ.get("CU2REC_EXCHANGE_OVERLAP")
+            overlap = (env == "1") if env in ("0", "1") else (self.world_size > 1 and dist.get_backend(group) == "nccl")
+        self.overlap = bool(overlap) and self.world_size > 1 and hasattr(engine, "apply_item_delta_overlapped")
+        self._pending = None
         if self.world_size > 1:
             engine.snapshot_items()
             if merge == "weighted":
@@ -65,10 +75,42 @@ class ShardedSGD:
                 if dev is not None:
                     self.item_weight = self.item_weight.to(dev)
 
-    def exchange(self):
-        """All-reduce the item-factor deltas and rebase every replica on the merged result."""
+    def _scale(self):
+        return 1.0 / self.world_size if self.merge == "mean" else 1.0  # weighted / sum: 1
+
+    def finish_pending(self):
+        """Fold in an all-reduce started by an earlier overlapped exchange (no-op if there is none)."""
+        if self._pending is None:
+            return
+        work, host = self._pending
+        work.wait()
+        if host is not None:
+            self.engine.exchange.copy_(host)
+        self.engine.apply_item_delta_overlapped(self._scale())
+        self._pending = None
+
+    def exchange(self, final=False):
+        """All-reduce the item-factor deltas and rebase every replica on the merged result.  With overlap the
+        collective is only STARTED here (and the previous one folded in); final=True drains it, so that every
+        replica holds the same item factors afterwards (used before a loss evaluation and at the end)."""
         self.since_sync = 0
         if self.world_size == 1:
+            return
+        if self.overlap:
+            self.finish_pending()
+            w = self.item_weight if self.merge == "weighted" else None
+            buf = self.engine.pack_item_delta(w) if w is not None else self.engine.pack_item_delta()
+            self.engine.snapshot_for_overlap()
+            host = None
+            if buf.is_cuda and dist.get_backend(self.group) != "nccl":
+                host = buf.cpu()
+                work = dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending = (work, host)
+            self.exchanges += 1
+            if final:
+                self.finish_pending()
             return
         buf = self.engine.pack_item_delta(self.item_weight) if self.merge == "weighted" else self.engine.pack_item_delta()
         if buf.is_cuda and dist.get_backend(self.group) != "nccl":
@@ -78,7 +120,7 @@ class ShardedSGD:
             buf.copy_(host)
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        self.engine.apply_item_delta(1.0 / self.world_size if self.merge == "mean" else 1.0)  # weighted / sum: 1
+        self.engine.apply_item_delta(self._scale())
         self.since_sync = 0
         self.exchanges += 1
 
@@ -160,8 +202,8 @@ def train_sharded(train, test, cfg, mode=api.SGD_HOGWILD, sync_every=0, merge="m
         n = seg_end - i + 1
         hyper = (cfg.learning_rate, cfg.P_reg, cfg.Q_reg, cfg.user_bias_reg, cfg.item_bias_reg)
         job.run(hyper, seed, iter_base + i, n, mode, bool(cfg.is_train))
-        if world_size > 1 and cfg.is_train and job.since_sync:
-            job.exchange()  # the loss below is taken on reconciled item factors
+        if world_size > 1 and cfg.is_train:
+            job.exchange(final=True)  # the loss below is taken on reconciled item factors
         tr_loss = job.loss(d_tr)
         last = validation_rmse
         te_loss = job.loss(d_te)

@@ -267,6 +267,13 @@ int cu2rec_csr_slice(const int *indptr, int rows, int u0, int u1, int *indptr_ou
  * between them the caller all-reduces `buf` (RCCL via torch.distributed or ncclAllReduce). */
 int cu2rec_items_delta_pack(const float *Q, const float *item_bias, const float *Q_base, const float *ib_base,
                             int n_cols, int ldq, float *buf, void *stream);
+/* Overlapped exchange: the all-reduce of `buf` runs while training continues.  *_snap hold Q / item_bias as they were
+ * when `buf` was packed; when the reduced `buf` arrives:
+ *     merged = Q_base + scale * buf;   Q = merged + (Q - Q_snap)   (local progress made meanwhile is kept);
+ *     Q_base = merged                  (so the next delta is exactly that local progress), same for item_bias. */
+int cu2rec_items_delta_apply_overlapped(float *Q, float *item_bias, float *Q_base, float *ib_base, const float *Q_snap,
+                                        const float *ib_snap, int n_cols, int ldq, const float *buf, float scale,
+                                        void *stream);
 /* Same with a per-item weight (device, n_cols floats) applied to the item's delta row and bias delta: ranks pack
  * w_k[y] * delta_k[y] with sum_k w_k[y] == 1, all-reduce(SUM), apply with scale 1 -- a per-item weighted average. */
 int cu2rec_items_delta_pack_weighted(const float *Q, const float *item_bias, const float *Q_base, const float *ib_base,

@@ -459,6 +459,21 @@ def test_item_exchange_kernels_and_rccl_world1():
         torch.testing.assert_close(eng.Q, Q1 + 0.5 * (Q2 - Q1), rtol=0, atol=1e-6)
         out = job.loss(DeviceRatings(te, eng.device))
         assert out["n"] == te.nnz and np.isfinite(out["rmse"])
+        # overlapped form: async RCCL all-reduce in flight while training continues, folded in afterwards
+        eng.snapshot_items()
+        base = eng.Q.clone()
+        eng.sgd(d, HYPER, 42, 20, 5, "hogwild")
+        buf = eng.pack_item_delta()
+        eng.snapshot_for_overlap()
+        snap = eng.Q.clone()
+        work = dist.all_reduce(buf, async_op=True)
+        eng.sgd(d, HYPER, 42, 25, 5, "hogwild")  # runs next to the collective
+        now = eng.Q.clone()
+        work.wait()
+        eng.apply_item_delta_overlapped(1.0)
+        torch.testing.assert_close(eng.Q_base, snap, rtol=0, atol=1e-6)          # merged = base + (snap - base)
+        torch.testing.assert_close(eng.Q, now, rtol=0, atol=2e-6)                # + local progress since the pack
+        assert not torch.equal(now, snap) and not torch.equal(snap, base)
     finally:
         dist.destroy_process_group()
 

@@ -64,6 +64,17 @@ class OracleEngine:
         self._buf = torch.from_numpy(np.concatenate([dQ.ravel(), dib]).astype(np.float32))
         return self._buf
 
+    def snapshot_for_overlap(self):
+        self.Q_snap, self.ib_snap = self.Q.copy(), self.ib.copy()
+        self.exchange = self._buf
+
+    def apply_item_delta_overlapped(self, scale):
+        d = self.exchange.numpy() * np.float32(scale)
+        n = self.Q.size
+        mQ, mib = self.Q_base + d[:n].reshape(self.Q.shape), self.ib_base + d[n:]
+        self.Q, self.ib = mQ + (self.Q - self.Q_snap), mib + (self.ib - self.ib_snap)
+        self.Q_base, self.ib_base = mQ, mib
+
     def apply_item_delta(self, scale):
         d = self._buf.numpy() * np.float32(scale)
         n = self.Q.size
@@ -245,3 +256,63 @@ def test_weighted_merge_two_ranks_gloo(tmp_path):
     only0 = (rates[0] > 0) & (rates[1] == 0)
     if only0.any():
         np.testing.assert_allclose(a["Q"][only0], (Q + deltas[0])[only0], atol=1e-6)
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tr, _ = synth.make_ratings(80, 25, 900, min_degree=2, seed=5)
+    f = 6
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    bounds = plan_users(tr.rows, world)
+    u0, u1 = bounds[rank], bounds[rank + 1]
+    eng = OracleEngine(u1 - u0, tr.cols, f, tr.global_bias, P[u0:u1], Q, ub[u0:u1], ib)
+    job = ShardedSGD(eng, tr.slice_users(u0, u1), user_offset=u0, sync_every=4, merge="mean", overlap=True)
+    assert job.overlap
+    job.run(HYPER, 42, 0, 12, cu.SGD_HOGWILD)  # all-reduces started after iterations 4, 8, 12; folded in one period late
+    assert job._pending is not None
+    job.finish_pending()
+    np.savez(os.path.join(out_dir, "o%d.npz" % rank), Q=eng.Q, ib=eng.ib, P=eng.P, exchanges=job.exchanges)
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_two_ranks_gloo(tmp_path):
+    """overlap=True: the all-reduce of period t is folded in at the end of period t+1; local progress made meanwhile
+    is kept on top of the merged base.  Checked against a single-process emulation of exactly that algebra."""
+    world, port = 2, 35000 + os.getpid() % 2000
+    mp.spawn(_overlap_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(str(tmp_path / ("o%d.npz" % k))) for k in range(world)]
+    assert int(r[0]["exchanges"]) == 3
+    tr, _ = synth.make_ratings(80, 25, 900, min_degree=2, seed=5)
+    f = 6
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    bounds = plan_users(tr.rows, world)
+    engs = [OracleEngine(bounds[k + 1] - bounds[k], tr.cols, f, tr.global_bias, P[bounds[k]:bounds[k + 1]], Q,
+                         ub[bounds[k]:bounds[k + 1]], ib) for k in range(world)]
+    shards = [tr.slice_users(bounds[k], bounds[k + 1]) for k in range(world)]
+    base_Q, base_ib = Q.copy(), ib.copy()
+    pending = None  # (sum of packed deltas, per-rank snapshots)
+    it = 0
+
+    def fold():
+        nonlocal base_Q, base_ib, pending
+        dQ, dib, snaps = pending
+        mQ, mib = base_Q + dQ / np.float32(world), base_ib + dib / np.float32(world)
+        for e, (sQ, sib) in zip(engs, snaps):
+            e.Q, e.ib = mQ + (e.Q - sQ), mib + (e.ib - sib)
+        base_Q, base_ib, pending = mQ, mib, None
+
+    for _ in range(3):
+        for k in range(world):
+            engs[k].sgd(shards[k], HYPER, 42, it, 4, cu.SGD_HOGWILD, True, bounds[k])
+        it += 4
+        if pending is not None:
+            fold()
+        pending = (sum(e.Q - base_Q for e in engs), sum(e.ib - base_ib for e in engs), [(e.Q.copy(), e.ib.copy()) for e in engs])
+    fold()
+    for k in range(world):
+        np.testing.assert_allclose(r[k]["Q"], engs[k].Q, atol=2e-6)
+        np.testing.assert_allclose(r[k]["ib"], engs[k].ib, atol=2e-6)
+        np.testing.assert_allclose(r[k]["P"], engs[k].P, atol=2e-6)
