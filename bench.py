@@ -318,7 +318,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "sgd_updates_per_sec", "value": value, "unit": "updates/s", "n_gpus": world,
+            "metric": "ratings/sec (SGD updates/sec)", "value": value, "unit": "updates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s-shape synthetic ratings (users %d, items %d, train nnz %d, test nnz %d per GPU), "

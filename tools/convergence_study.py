@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
-"""Test-RMSE trajectory of the GPU SGD modes next to the sequential CPU oracle, same data, same sampler
-stream (tools/, not shipped in the product path; uses the oracle as the checker).
+"""Test-RMSE trajectory of the GPU SGD modes on the same data and the same sampler stream.  `ordered` IS the
+sequential (mf_sequential.cu) trajectory -- the parity tests show it bit-identical to the CPU oracle -- so it serves
+as the reference curve here; this tool itself never touches oracle/.
 
-usage: tools/convergence_study.py [--workload ml-1m] [--factors 50] [--iters 2000] [--every 250] [--modes hogwild,...]
+usage: tools/convergence_study.py [--workload ml-1m] [--factors 50] [--iters 2000] [--every 250]
+                                  [--modes hogwild,hogwild:4,ordered]     (mode:k = k iterations per Hogwild launch)
 """
 import argparse
 import json
@@ -22,13 +24,11 @@ def main():
     ap.add_argument("--factors", type=int, default=50)
     ap.add_argument("--iters", type=int, default=2000)
     ap.add_argument("--every", type=int, default=250)
-    ap.add_argument("--modes", default="hogwild")
+    ap.add_argument("--modes", default="hogwild,ordered")
     ap.add_argument("--lr", type=float, default=0.01)
-    ap.add_argument("--no-oracle", action="store_true")
     args = ap.parse_args()
     import bench
     import cu2rec_amd as cu
-    from oracle import oracle as orc
     train, test = bench.load_dataset(args.workload, 20240917, 0, lambda: None)
     f, hyper = args.factors, (args.lr, 0.02, 0.02, 0.02, 0.02)
     d_tr, d_te = cu.DeviceCSR(train), cu.DeviceCSR(test)
@@ -50,18 +50,6 @@ def main():
         mode = mode if block == 1 else "%s_x%d" % (mode, block)
         out["curves"][mode] = {"points": curve, "seconds": t_sgd}
         print(mode, "%.2fs" % t_sgd, " ".join("%d:%.5f" % (a, b) for a, b, _ in curve), flush=True)
-    if not args.no_oracle:
-        o_tr = orc.CSR(train.indptr, train.indices, train.data, train.rows, train.cols, train.global_bias)
-        o_te = orc.CSR(test.indptr, test.indices, test.data, test.rows, test.cols, test.global_bias)
-        P, Q, ub, ib = orc.init_model(train.rows, train.cols, f)
-        curve = [(0, orc.loss(o_te, P, Q, ub, ib, train.global_bias)["rmse"], orc.loss(o_tr, P, Q, ub, ib, train.global_bias)["rmse"])]
-        t0 = time.perf_counter()
-        for it in range(0, args.iters, args.every):
-            orc.sgd_iterations(o_tr, P, Q, ub, ib, train.global_bias, hyper, 42, it, args.every, dot_order=orc.DOT_TREE16)
-            curve.append((it + args.every, orc.loss(o_te, P, Q, ub, ib, train.global_bias)["rmse"],
-                          orc.loss(o_tr, P, Q, ub, ib, train.global_bias)["rmse"]))
-        out["curves"]["oracle_sequential"] = {"points": curve, "seconds": time.perf_counter() - t0}
-        print("oracle", "%.2fs" % (time.perf_counter() - t0), " ".join("%d:%.5f" % (a, b) for a, b, _ in curve), flush=True)
     print(json.dumps(out))
 
 
