@@ -299,47 +299,94 @@ __device__ __forceinline__ void run_hot_chain_wide(const SgdArgs &a, const uint6
 //                      published and store them, publish tile k+1.
 // W = lanes per chain: 32 (one slot per lane, 65 <= ld <= 128) or 16 (ld <= 64); wave 0 computes 64 / W chains,
 // waves 1 and 2 move their memory
-constexpr int kDuoTile = 8;    // updates per tile (one barrier per tile)
-constexpr int kDuoPart = 4;    // entries of a tile handled by each of the two memory waves
+// Shape of the two-wave form for a row of S float4 slots per lane:
+//   W      lanes per chain: 32 with S == 1 (65 <= ld <= 128: one slot per lane, s_l + s_{l+16} by v_permlane16_swap),
+//          16 otherwise (the 16-lane layout of the other kernels, S slots per lane)
+//   tile   updates between two barriers; part = the share of each of the two memory waves
+//   chains chains per hot block, limited by the 64 KB of static LDS a block may declare
+template <int W, int S>
+struct DuoShape {
+    static_assert(W == kGroup || S == 1, "the 32-lane layout holds exactly one slot per lane");
+    static constexpr int kTile = S == 1 ? 8 : 4;
+    static constexpr int kPart = kTile / 2;
+    static constexpr int kChains = W == kWide ? 2 : (S <= 3 ? 4 : (S <= 6 ? 2 : 1));
+};
 
-template <int W>
+template <int S>
+struct WideRow {  // a lane's share of a factor row: slots lane, lane + W, ...
+    float4 v[S];
+};
+
+template <int W, int S>
 struct DuoLds {
-    float4 p[2][kDuoTile][W];     // user rows of the tile, as loaded
-    float4 qold[2][kDuoTile][W];  // item row before each update of the tile (written by A)
-    float rating[2][kDuoTile], ub[2][kDuoTile], err[2][kDuoTile];
-    int user[2][kDuoTile];
+    static constexpr int T = DuoShape<W, S>::kTile;
+    float4 p[2][T][S][W];     // user rows of the tile, as loaded
+    float4 qold[2][T][S][W];  // item row before each update of the tile (written by A)
+    float rating[2][T], ub[2][T], err[2][T];
+    int user[2][T];
 };
 
+template <int W, int S>
 struct DuoTileRegs {  // one memory wave's share of a tile
-    float4 rows[kDuoPart];
-    uint64_t val;  // lanes 0..3: entry (user << 32 | rating bits)
-    float ub;      // lanes 0..3: user bias
+    WideRow<S> rows[DuoShape<W, S>::kPart];
+    uint64_t val;  // lanes 0..part-1: entry (user << 32 | rating bits)
+    float ub;      // lanes 0..part-1: user bias
 };
 
-// entries [tile_start + 4 * part, +4) of the chain, one per lane 0..3 (mirrored on the other lanes)
-__device__ __forceinline__ uint64_t duo_load_vals(const uint64_t *__restrict__ vals, int tile_start, int end, int part,
-                                                  int lane32) {
-    return vals[min(tile_start + kDuoPart * part + (lane32 & (kDuoPart - 1)), end - 1)];  // past the chain: its last entry, never used
+template <int W, int S>
+__device__ __forceinline__ WideRow<S> load_wide_row(const float *__restrict__ base, size_t row, int ld, int nslots, int lane) {
+    const float4 *p = reinterpret_cast<const float4 *>(base + row * static_cast<size_t>(ld));
+    WideRow<S> r;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int slot = lane + W * s;
+        const float4 v = p[min(slot, nslots - 1)];  // branch free: out-of-row lanes re-read the last slot and drop it
+        const bool ok = slot < nslots;
+        r.v[s] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+    }
+    return r;
 }
 
-template <int W>
-__device__ __forceinline__ void duo_load_rows(DuoTileRegs &r, const SgdArgs &a, uint64_t val, int lane32) {
+template <int W, int S>
+__device__ __forceinline__ void store_wide_row(float *__restrict__ base, size_t row, int ld, int nslots, int lane,
+                                               const WideRow<S> &r) {
+    float4 *p = reinterpret_cast<float4 *>(base + row * static_cast<size_t>(ld));
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int slot = lane + W * s;
+        if (slot < nslots) p[slot] = r.v[s];
+    }
+}
+
+// this wave's entries of the tile starting at tile_start, one per lane 0..part-1 (mirrored on the other lanes)
+template <int W, int S>
+__device__ __forceinline__ uint64_t duo_load_vals(const uint64_t *__restrict__ vals, int tile_start, int end, int part,
+                                                  int lane) {
+    constexpr int kPart = DuoShape<W, S>::kPart;
+    return vals[min(tile_start + kPart * part + (lane & (kPart - 1)), end - 1)];  // past the chain: its last entry, never used
+}
+
+template <int W, int S>
+__device__ __forceinline__ void duo_load_rows(DuoTileRegs<W, S> &r, const SgdArgs &a, uint64_t val, int lane) {
     r.val = val;
     const int my_user = static_cast<int>(val >> 32);
     r.ub = a.user_bias[my_user];
 #pragma unroll
-    for (int t = 0; t < kDuoPart; ++t) {
+    for (int t = 0; t < DuoShape<W, S>::kPart; ++t) {
         const int x = __shfl(my_user, t, W);
-        r.rows[t] = load_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32);
+        r.rows[t] = load_wide_row<W, S>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
     }
 }
 
-template <int W>
-__device__ __forceinline__ void duo_publish(DuoLds<W> &l, int buf, const DuoTileRegs &r, int part, int lane32) {
+template <int W, int S>
+__device__ __forceinline__ void duo_publish(DuoLds<W, S> &l, int buf, const DuoTileRegs<W, S> &r, int part, int lane) {
+    constexpr int kPart = DuoShape<W, S>::kPart;
 #pragma unroll
-    for (int t = 0; t < kDuoPart; ++t) l.p[buf][kDuoPart * part + t][lane32] = r.rows[t];
-    if (lane32 < kDuoPart) {
-        const int e = kDuoPart * part + lane32;
+    for (int t = 0; t < kPart; ++t)
+#pragma unroll
+        for (int s = 0; s < S; ++s) l.p[buf][kPart * part + t][s][lane] = r.rows[t].v[s];
+    if (lane < kPart) {
+        const int e = kPart * part + lane;
         l.rating[buf][e] = __uint_as_float(static_cast<uint32_t>(r.val));
         l.ub[buf][e] = r.ub;
         l.user[buf][e] = static_cast<int>(r.val >> 32);
@@ -348,69 +395,86 @@ __device__ __forceinline__ void duo_publish(DuoLds<W> &l, int buf, const DuoTile
 
 // B: the user side of this wave's share of a finished tile (mf_sequential.cu:133-135,140 with the item row as it
 // was at that update)
-template <int W>
-__device__ __forceinline__ void duo_update_users(DuoLds<W> &l, int buf, int n_valid, const SgdArgs &a, int part, int lane32) {
+template <int W, int S>
+__device__ __forceinline__ void duo_update_users(DuoLds<W, S> &l, int buf, int n_valid, const SgdArgs &a, int part, int lane) {
+    constexpr int kPart = DuoShape<W, S>::kPart;
 #pragma unroll
-    for (int t = 0; t < kDuoPart; ++t) {
-        const int e = kDuoPart * part + t;
+    for (int t = 0; t < kPart; ++t) {
+        const int e = kPart * part + t;
         if (e < n_valid) {
-            const float4 po = l.p[buf][e][lane32], qo = l.qold[buf][e][lane32];
             const float err = l.err[buf][e];
-            float4 pn;
-            pn.x = step(po.x, qo.x, err, a.h.lr, a.h.p_reg);
-            pn.y = step(po.y, qo.y, err, a.h.lr, a.h.p_reg);
-            pn.z = step(po.z, qo.z, err, a.h.lr, a.h.p_reg);
-            pn.w = step(po.w, qo.w, err, a.h.lr, a.h.p_reg);
-            store_wide(a.P, static_cast<size_t>(l.user[buf][e]), a.ldp, a.nslots, lane32, pn);
+            WideRow<S> pn;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float4 po = l.p[buf][e][s][lane], qo = l.qold[buf][e][s][lane];
+                pn.v[s].x = step(po.x, qo.x, err, a.h.lr, a.h.p_reg);
+                pn.v[s].y = step(po.y, qo.y, err, a.h.lr, a.h.p_reg);
+                pn.v[s].z = step(po.z, qo.z, err, a.h.lr, a.h.p_reg);
+                pn.v[s].w = step(po.w, qo.w, err, a.h.lr, a.h.p_reg);
+            }
+            store_wide_row<W, S>(a.P, static_cast<size_t>(l.user[buf][e]), a.ldp, a.nslots, lane, pn);
         }
     }
-    const int mine = kDuoPart * part + lane32;
-    if (lane32 < kDuoPart && mine < n_valid) {
+    const int mine = kPart * part + lane;
+    if (lane < kPart && mine < n_valid) {
         const float ub = l.ub[buf][mine], err = l.err[buf][mine];
         a.user_bias[l.user[buf][mine]] = ub + a.h.lr * (err - a.h.ub_reg * ub);
     }
 }
 
-// A: the dependent chain of one update (same operations, same order as chain_step_wide); the user's row, rating
-// and bias arrive in registers.
-template <int W>
-__device__ __forceinline__ void duo_step_a(DuoLds<W> &l, int buf, int t, const float4 &po, float rating, float ub,
-                                           const SgdArgs &a, float4 &q, float &ib, int lane32) {
-    const float s = slot_dot(q, po);
-    const float dot = W == kWide ? row_sum16(cross_row_sum(s)) : row_sum16(s);  // canonical order either way
+// A: the dependent chain of one update (same operations, same order as predict<J> + rank1_update<J>'s item half); the
+// user's row, rating and bias arrive in registers.
+template <int W, int S>
+__device__ __forceinline__ void duo_step_a(DuoLds<W, S> &l, int buf, int t, const WideRow<S> &po, float rating, float ub,
+                                           const SgdArgs &a, WideRow<S> &q, float &ib, int lane) {
+    float acc = slot_dot(q.v[0], po.v[0]);
+#pragma unroll
+    for (int s = 1; s < S; ++s) acc = acc + slot_dot(q.v[s], po.v[s]);
+    const float dot = W == kWide ? row_sum16(cross_row_sum(acc)) : row_sum16(acc);  // canonical order either way
     const float err = rating - (((a.global_bias + ub) + ib) + dot);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const float4 qo = q.v[s];
 #if !(CU2REC_ABLATE & 16)
-    l.qold[buf][t][lane32] = q;
-    if (lane32 == 0) l.err[buf][t] = err;
+        l.qold[buf][t][s][lane] = qo;
 #endif
-    const float4 qo = q;
-    q.x = step(qo.x, po.x, err, a.h.lr, a.h.q_reg);
-    q.y = step(qo.y, po.y, err, a.h.lr, a.h.q_reg);
-    q.z = step(qo.z, po.z, err, a.h.lr, a.h.q_reg);
-    q.w = step(qo.w, po.w, err, a.h.lr, a.h.q_reg);
+        q.v[s].x = step(qo.x, po.v[s].x, err, a.h.lr, a.h.q_reg);
+        q.v[s].y = step(qo.y, po.v[s].y, err, a.h.lr, a.h.q_reg);
+        q.v[s].z = step(qo.z, po.v[s].z, err, a.h.lr, a.h.q_reg);
+        q.v[s].w = step(qo.w, po.v[s].w, err, a.h.lr, a.h.q_reg);
+    }
+#if !(CU2REC_ABLATE & 16)
+    if (lane == 0) l.err[buf][t] = err;
+#endif
     ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
 }
 
-template <int W>
-__device__ __forceinline__ void duo_compute(DuoLds<W> &l, int buf, int n_valid, const SgdArgs &a, float4 &q, float &ib,
-                                            int lane32) {
-    if (n_valid == kDuoTile) {
-        // full tile: fetch everything the 8 updates need from LDS up front (one latency per tile, not per update);
+template <int W, int S>
+__device__ __forceinline__ void duo_compute(DuoLds<W, S> &l, int buf, int n_valid, const SgdArgs &a, WideRow<S> &q,
+                                            float &ib, int lane) {
+    constexpr int T = DuoShape<W, S>::kTile;
+    if (n_valid == T) {
+        // full tile: fetch everything its updates need from LDS up front (one latency per tile, not per update);
         // the scheduling barrier keeps the compiler from sinking the reads back next to their uses
-        float4 po[kDuoTile];
-        float rating[kDuoTile], ub[kDuoTile];
+        WideRow<S> po[T];
+        float rating[T], ub[T];
 #pragma unroll
-        for (int t = 0; t < kDuoTile; ++t) {
-            po[t] = l.p[buf][t][lane32];
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) po[t].v[s] = l.p[buf][t][s][lane];
             rating[t] = l.rating[buf][t];
             ub[t] = l.ub[buf][t];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < kDuoTile; ++t) duo_step_a<W>(l, buf, t, po[t], rating[t], ub[t], a, q, ib, lane32);
+        for (int t = 0; t < T; ++t) duo_step_a<W, S>(l, buf, t, po[t], rating[t], ub[t], a, q, ib, lane);
     } else {
-        for (int t = 0; t < n_valid; ++t)
-            duo_step_a<W>(l, buf, t, l.p[buf][t][lane32], l.rating[buf][t], l.ub[buf][t], a, q, ib, lane32);
+        for (int t = 0; t < n_valid; ++t) {
+            WideRow<S> po;
+#pragma unroll
+            for (int s = 0; s < S; ++s) po.v[s] = l.p[buf][t][s][lane];
+            duo_step_a<W, S>(l, buf, t, po, l.rating[buf][t], l.ub[buf][t], a, q, ib, lane);
+        }
     }
 }
 
@@ -424,27 +488,29 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
     return lo;
 }
 
-// One hot block: 64 / W chains; wave 0 computes (W lanes per chain), waves 1 and 2 each move half of every tile's
-// memory traffic, wave 3 only keeps the barriers company.
-template <int W>
+// One hot block: up to 64 / W chains; wave 0 computes (W lanes per chain), waves 1 and 2 each move half of every
+// tile's memory traffic, wave 3 only keeps the barriers company.
+template <int W, int S>
 __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32_t *__restrict__ keys,
                                                   const uint64_t *__restrict__ vals, int n_active, uint32_t key_base,
                                                   int n_hot, const int *__restrict__ item_of_rank) {
-    constexpr int kChains = 64 / W;
-    __shared__ DuoLds<W> lds[kChains];
+    constexpr int kChains = DuoShape<W, S>::kChains, kTile = DuoShape<W, S>::kTile;
+    __shared__ DuoLds<W, S> lds[kChains];
     __shared__ int s_range[kChains][2];
-    const int wave = threadIdx.x >> 6, lane32 = threadIdx.x & (W - 1);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (W - 1);
     const bool role_a = wave == 0, role_b = wave == 1 || wave == 2;
-    const int part = wave - 1;                // memory waves: which half of the tile
-    const int c = (threadIdx.x & 63) / W;      // chain of this lane group
+    const int part = wave - 1;                       // memory waves: which half of the tile
+    const int group = (threadIdx.x & 63) / W;        // lane group inside the wave
+    const bool has_chain = group < kChains;          // blocks of fat rows use only some of the groups
+    const int c = has_chain ? group : 0;
     const int r = blockIdx.x * kChains + c;
-    if (role_a) {
+    if (role_a && has_chain) {
         int begin = 0, end = 0;
         if (r < n_hot) {
             begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
             end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));
         }
-        if (lane32 == 0) {
+        if (lane == 0) {
             s_range[c][0] = begin;
             s_range[c][1] = end;
         }
@@ -454,42 +520,44 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     int longest = 0;
 #pragma unroll
     for (int i = 0; i < kChains; ++i) longest = max(longest, s_range[i][1] - s_range[i][0]);
-    const int n_tiles = (longest + kDuoTile - 1) / kDuoTile;  // block uniform: every wave runs the same barriers
+    const int n_tiles = (longest + kTile - 1) / kTile;  // block uniform: every wave runs the same barriers
     if (n_tiles == 0) return;
-    const bool alive = len > 0 && (role_a || role_b);
-    DuoLds<W> &l = lds[c];
+    const bool alive = len > 0 && has_chain && (role_a || role_b);
+    DuoLds<W, S> &l = lds[c];
     const int y = alive ? item_of_rank[r] : 0;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    WideRow<S> q;
+#pragma unroll
+    for (int s = 0; s < S; ++s) q.v[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     float ib = 0.f;
     // A memory wave keeps two register tiles and alternates their roles each phase (no copies: a copy would wait for
     // the loads just issued): at the start of phase k, r0 / r1 (by parity of k) holds its share of tile k+1 -- loads
     // issued a whole phase ago -- and the other one receives tile k+2.
-    DuoTileRegs r0, r1;
+    DuoTileRegs<W, S> r0, r1;
     uint64_t v_next = 0;  // this wave's entries of tile k+2 at the start of phase k
     if (alive && role_b) {
-        const uint64_t v0 = duo_load_vals(vals, begin, end, part, lane32);
-        const uint64_t v1 = duo_load_vals(vals, begin + kDuoTile, end, part, lane32);
-        v_next = duo_load_vals(vals, begin + 2 * kDuoTile, end, part, lane32);
-        duo_load_rows<W>(r1, a, v0, lane32);
-        duo_load_rows<W>(r0, a, v1, lane32);
-        duo_publish<W>(l, 0, r1, part, lane32);
+        const uint64_t v0 = duo_load_vals<W, S>(vals, begin, end, part, lane);
+        const uint64_t v1 = duo_load_vals<W, S>(vals, begin + kTile, end, part, lane);
+        v_next = duo_load_vals<W, S>(vals, begin + 2 * kTile, end, part, lane);
+        duo_load_rows<W, S>(r1, a, v0, lane);
+        duo_load_rows<W, S>(r0, a, v1, lane);
+        duo_publish<W, S>(l, 0, r1, part, lane);
     } else if (alive) {
-        q = load_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32);
+        q = load_wide_row<W, S>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
         ib = a.item_bias[y];
     }
     __syncthreads();
-    auto b_phase = [&](int k, DuoTileRegs &ready, DuoTileRegs &loading) {
-        const uint64_t v_after = duo_load_vals(vals, begin + (k + 3) * kDuoTile, end, part, lane32);
+    auto b_phase = [&](int k, DuoTileRegs<W, S> &ready, DuoTileRegs<W, S> &loading) {
+        const uint64_t v_after = duo_load_vals<W, S>(vals, begin + (k + 3) * kTile, end, part, lane);
 #if !(CU2REC_ABLATE & 32)
-        duo_load_rows<W>(loading, a, v_next, lane32);  // tile k + 2
+        duo_load_rows<W, S>(loading, a, v_next, lane);  // tile k + 2
 #endif
 #if !(CU2REC_ABLATE & 8)
-        if (k >= 1) duo_update_users<W>(l, (k - 1) & 1, min(max(len - (k - 1) * kDuoTile, 0), kDuoTile), a, part, lane32);
+        if (k >= 1) duo_update_users<W, S>(l, (k - 1) & 1, min(max(len - (k - 1) * kTile, 0), kTile), a, part, lane);
 #endif
-        duo_publish<W>(l, (k + 1) & 1, ready, part, lane32);  // tile k + 1, after the reads of that buffer just above
+        duo_publish<W, S>(l, (k + 1) & 1, ready, part, lane);  // tile k + 1, after the reads of that buffer just above
         v_next = v_after;
     };
-    auto a_phase = [&](int k) { duo_compute<W>(l, k & 1, min(max(len - k * kDuoTile, 0), kDuoTile), a, q, ib, lane32); };
+    auto a_phase = [&](int k) { duo_compute<W, S>(l, k & 1, min(max(len - k * kTile, 0), kTile), a, q, ib, lane); };
     for (int k = 0; k < n_tiles; k += 2) {
         if (alive) {
             if (role_b) b_phase(k, r0, r1); else a_phase(k);
@@ -504,10 +572,10 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     }
     if (alive) {
         if (role_b) {
-            duo_update_users<W>(l, (n_tiles - 1) & 1, min(max(len - (n_tiles - 1) * kDuoTile, 0), kDuoTile), a, part, lane32);
+            duo_update_users<W, S>(l, (n_tiles - 1) & 1, min(max(len - (n_tiles - 1) * kTile, 0), kTile), a, part, lane);
         } else {
-            store_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32, q);
-            if (lane32 == 0) a.item_bias[y] = ib;
+            store_wide_row<W, S>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
+            if (lane == 0) a.item_bias[y] = ib;
         }
     }
 }
@@ -532,10 +600,9 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
     const int lane = threadIdx.x & (kGroup - 1);
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
 #if CU2REC_HOT_DUO
-        if constexpr (J <= 2) {
-            run_hot_block_duo<(J == 2 ? kWide : kGroup)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank);
-            return;
-        }
+        // two-wave form for every row width: 32 lanes x 1 slot when 65 <= ld <= 128, else 16 lanes x J slots
+        run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank);
+        return;
 #else
         if constexpr (J == 2) {
             // single-wave wide layout: half a wavefront per chain does everything
@@ -639,8 +706,9 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream) {
-    // hot blocks: two-wave form for ld <= 128 (64 / W chains per block), one group per chain otherwise
-    const int chains_per_block = CU2REC_HOT_DUO ? (J == 2 ? 2 : (J == 1 ? 4 : kGroupsPerBlock)) : (J == 2 ? kBlock / kWide : kGroupsPerBlock);
+    // hot blocks: the two-wave form holds DuoShape::kChains chains per block; the legacy forms one per lane group
+    const int chains_per_block = CU2REC_HOT_DUO ? DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains
+                                                 : (J == 2 ? kBlock / kWide : kGroupsPerBlock);
     const int hot_blocks = (n_hot + chains_per_block - 1) / chains_per_block;
     const int groups = (n_active + kWindow - 1) / kWindow;
     const int blocks = hot_blocks + (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
