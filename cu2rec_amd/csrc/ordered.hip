@@ -83,209 +83,22 @@ __device__ __forceinline__ float chain_step(const SgdArgs &a, Row<J> &p, Row<J> 
     return ub + a.h.lr * (err - a.h.ub_reg * ub);                         // :140 (new user bias)
 }
 
-// ---- hot chains: 16-entry chunks, user rows fetched one tile ahead -----------------------------------------
-// Everything here is branch free on purpose: with straight-line code the compiler keeps the next tile's row
-// loads (and the next chunk's entry / bias loads) in flight behind counted s_waitcnt while the current tile
-// computes; with per-entry predicates it falls back to s_waitcnt vmcnt(0) after every load.
-
-// entry (user << 32 | rating bits) and user bias of 16 consecutive chain entries, one per lane
-struct ChunkMeta {
-    uint64_t val;
-    float ub;
-};
-
-__device__ __forceinline__ ChunkMeta load_meta(const SgdArgs &a, const uint64_t *__restrict__ vals, int s, int lane) {
-    ChunkMeta m;
-    m.val = vals[s + lane];
-    m.ub = a.user_bias[static_cast<int>(m.val >> 32)];
-    return m;
-}
-
-// row load without control flow: lanes whose slot is past the row read the row's last slot and discard it
-template <int J>
-__device__ __forceinline__ Row<J> load_row_nb(const float *__restrict__ base, size_t row, int ld, int nslots, int lane) {
-    const float4 *p = reinterpret_cast<const float4 *>(base + row * static_cast<size_t>(ld));
-    Row<J> r;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int slot = lane + kGroup * j;
-        const float4 v = p[min(slot, nslots - 1)];
-        const bool ok = slot < nslots;
-        r.v[j] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-    }
-    return r;
-}
-
-template <int J, int T>
-struct RowTile {
-    Row<J> rows[T];
-};
-
-// rows of entries [first, first + T) of the chunk described by m
-template <int J, int T>
-__device__ __forceinline__ void load_rows(RowTile<J, T> &tile, const SgdArgs &a, const ChunkMeta &m, int first, int lane) {
-    const int my_user = static_cast<int>(m.val >> 32);
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int x = __shfl(my_user, first + t, kGroup);
-        tile.rows[t] = load_row_nb<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
-    }
-}
-
-template <int J, int T>
-__device__ __forceinline__ void run_rows(RowTile<J, T> &tile, const SgdArgs &a, const ChunkMeta &m, int first,
-                                         Row<J> &q, float &ib, float &my_new_ub, int lane) {
-    const int my_user = static_cast<int>(m.val >> 32);
-    const float my_rating = __uint_as_float(static_cast<uint32_t>(m.val));
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int x = __shfl(my_user, first + t, kGroup);
-        const float rating = __shfl(my_rating, first + t, kGroup);
-        const float ub = __shfl(m.ub, first + t, kGroup);
-        const float new_ub = chain_step<J>(a, tile.rows[t], q, ub, ib, rating);
-        store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, tile.rows[t]);
-        my_new_ub = lane == first + t ? new_ub : my_new_ub;
-    }
-}
-
-// ---- hot chains, wide layout (J == 2, i.e. 65 <= ld <= 128): one float4 slot per lane over 32 lanes ----------
-// Half a wavefront owns one chain.  Per update every lane then carries 4 factors instead of 8, which halves the
-// element-wise work on the chain's critical path; the dot product keeps the canonical order (sgd_device.hpp):
-// slot partials s_0..s_31, then s_l + s_{l+16} -- here ONE v_permlane16_swap + add across the two 16-lane rows --
-// then the 16-lane butterfly, so the bits equal the 16-lane kernels'.
 #ifndef CU2REC_ABLATE
-#define CU2REC_ABLATE 0
-#endif
-#ifndef CU2REC_HOT_DUO
-#define CU2REC_HOT_DUO 1  // hot chains with ld <= 128: compute wave + memory waves through LDS (0: one lane group does it all)
-#endif
-constexpr int kWide = 32;
+#define CU2REC_ABLATE 0  // timing-only builds of the hot path: 8 = no user-side updates, 16 = no LDS publishes by the
+#endif                   // compute wave, 32 = no row loads (results are wrong; never set in the shipped library)
+
+constexpr int kWide = 32;  // lanes per chain in the wide layout (one float4 slot per lane, 65 <= ld <= 128)
 
 typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
 
+// Wide layout only: adds the two 16-lane rows of a half-wavefront, s_l + s_{l+16} of the canonical order.
 __device__ __forceinline__ float cross_row_sum(float v) {
     // rows (r0, r1) -> both operands hold (r0 | r0) and (r1 | r1): the sum is r0 + r1 in every lane of both rows
     const uint2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
-__device__ __forceinline__ float4 load_wide(const float *__restrict__ base, size_t row, int ld, int nslots, int lane32) {
-    const float4 *p = reinterpret_cast<const float4 *>(base + row * static_cast<size_t>(ld));
-    const float4 v = p[min(lane32, nslots - 1)];  // branch free: out-of-row lanes re-read the last slot ...
-    const bool ok = lane32 < nslots;              // ... and drop it
-    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-}
-
-__device__ __forceinline__ void store_wide(float *__restrict__ base, size_t row, int ld, int nslots, int lane32,
-                                           const float4 &v) {
-    float4 *p = reinterpret_cast<float4 *>(base + row * static_cast<size_t>(ld));
-    if (lane32 < nslots) p[lane32] = v;
-}
-
-// one chain update in the wide layout; same operations, same order as chain_step<2>
-__device__ __forceinline__ float chain_step_wide(const SgdArgs &a, float4 &p, float4 &q, float ub, float &ib, float rating) {
-    const float dot = row_sum16(cross_row_sum(slot_dot(q, p)));
-    const float err = rating - (((a.global_bias + ub) + ib) + dot);
-    const float4 po = p, qo = q;
-    p.x = step(po.x, qo.x, err, a.h.lr, a.h.p_reg);
-    p.y = step(po.y, qo.y, err, a.h.lr, a.h.p_reg);
-    p.z = step(po.z, qo.z, err, a.h.lr, a.h.p_reg);
-    p.w = step(po.w, qo.w, err, a.h.lr, a.h.p_reg);
-    q.x = step(qo.x, po.x, err, a.h.lr, a.h.q_reg);
-    q.y = step(qo.y, po.y, err, a.h.lr, a.h.q_reg);
-    q.z = step(qo.z, po.z, err, a.h.lr, a.h.q_reg);
-    q.w = step(qo.w, po.w, err, a.h.lr, a.h.q_reg);
-    ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
-    return ub + a.h.lr * (err - a.h.ub_reg * ub);
-}
-
-template <int T>
-struct WideTile {
-    float4 rows[T];
-};
-
-template <int T>
-__device__ __forceinline__ void load_wide_rows(WideTile<T> &tile, const SgdArgs &a, const ChunkMeta &m, int first, int lane32) {
-    const int my_user = static_cast<int>(m.val >> 32);
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-#if CU2REC_ABLATE & 4
-        tile.rows[t] = make_float4(0.01f * t, 0.02f, 0.03f, 0.04f);  // timing only: no row loads
-#else
-        const int x = __shfl(my_user, first + t, kWide);
-        tile.rows[t] = load_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32);
-#endif
-    }
-}
-
-template <int T>
-__device__ __forceinline__ void run_wide_rows(WideTile<T> &tile, const SgdArgs &a, const ChunkMeta &m, int first,
-                                              float4 &q, float &ib, float &my_new_ub, int lane32) {
-    const int my_user = static_cast<int>(m.val >> 32);
-    const float my_rating = __uint_as_float(static_cast<uint32_t>(m.val));
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-#if CU2REC_ABLATE & 2
-        const int x = my_user + t;  // timing only: no cross-lane traffic
-        const float rating = my_rating;
-        const float ub = m.ub;
-#else
-        const int x = __shfl(my_user, first + t, kWide);
-        const float rating = __shfl(my_rating, first + t, kWide);
-        const float ub = __shfl(m.ub, first + t, kWide);
-#endif
-        const float new_ub = chain_step_wide(a, tile.rows[t], q, ub, ib, rating);
-#if !(CU2REC_ABLATE & 1)
-        store_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32, tile.rows[t]);
-#endif
-        my_new_ub = lane32 == first + t ? new_ub : my_new_ub;
-    }
-}
-
-// whole chain [begin, end) of item y in the wide layout: 32-entry chunks (entries / biases fetched a chunk ahead),
-// rows fetched a tile of 8 ahead
-__device__ __forceinline__ void run_hot_chain_wide(const SgdArgs &a, const uint64_t *__restrict__ vals, int begin, int end,
-                                                   int y, int lane32) {
-    constexpr int T = 8;
-    float4 q = load_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32);
-    float ib = a.item_bias[y];
-    const int n_chunks = (end - begin) / kWide;
-    int s = begin;
-    if (n_chunks > 0) {
-        const int last_chunk = begin + (n_chunks - 1) * kWide;
-        WideTile<T> ra, rb;
-        ChunkMeta cur = load_meta(a, vals, s, lane32);
-        load_wide_rows<T>(ra, a, cur, 0, lane32);
-        for (int c = 0; c < n_chunks; ++c) {
-            const ChunkMeta nxt = load_meta(a, vals, min(s + kWide, last_chunk), lane32);
-            float my_new_ub = 0.f;
-            load_wide_rows<T>(rb, a, cur, 8, lane32);
-            run_wide_rows<T>(ra, a, cur, 0, q, ib, my_new_ub, lane32);
-            load_wide_rows<T>(ra, a, cur, 16, lane32);
-            run_wide_rows<T>(rb, a, cur, 8, q, ib, my_new_ub, lane32);
-            load_wide_rows<T>(rb, a, cur, 24, lane32);
-            run_wide_rows<T>(ra, a, cur, 16, q, ib, my_new_ub, lane32);
-            load_wide_rows<T>(ra, a, nxt, 0, lane32);  // last chunk: a discarded re-load
-            run_wide_rows<T>(rb, a, cur, 24, q, ib, my_new_ub, lane32);
-            a.user_bias[static_cast<int>(cur.val >> 32)] = my_new_ub;  // 32 users, one store
-            cur = nxt;
-            s += kWide;
-        }
-    }
-    for (; s < end; ++s) {  // fewer than 32 entries left
-        const uint64_t val = vals[s];
-        const int x = static_cast<int>(val >> 32);
-        float4 p = load_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32);
-        const float ub = a.user_bias[x];
-        const float new_ub = chain_step_wide(a, p, q, ub, ib, __uint_as_float(static_cast<uint32_t>(val)));
-        store_wide(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane32, p);
-        if (lane32 == 0) a.user_bias[x] = new_ub;
-    }
-    store_wide(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane32, q);
-    if (lane32 == 0) a.item_bias[y] = ib;
-}
-
-// ---- hot chains, two-wave form (J == 2): a compute wave and a memory wave per pair of chains -------------------
+// ---- hot chains: a compute wave and two memory waves per block --------------------------------------------------
 // The chain is latency bound: per update a ~17-deep dependent chain (slot dot, cross-row add, butterfly, error,
 // item-row update).  Everything that is NOT on that chain -- fetching the next users' rows, updating and storing
 // the user's row, the user bias -- is moved to a second wavefront of the same workgroup, which talks to the first
@@ -580,11 +393,6 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     }
 }
 
-template <int J>
-struct HotTile {
-    static constexpr int value = J <= 2 ? 4 : (J <= 4 ? 2 : 1);
-};
-
 // One launch = one iteration.  Two roles, chosen per block:
 //  * blocks [0, hot_blocks): one group per popularity rank r < n_hot.  These are the long chains (thousands of
 //    updates on the most rated items); the chain is the critical path of the iteration, so its user rows are
@@ -599,76 +407,8 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
                                                              int hot_blocks) {
     const int lane = threadIdx.x & (kGroup - 1);
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
-#if CU2REC_HOT_DUO
         // two-wave form for every row width: 32 lanes x 1 slot when 65 <= ld <= 128, else 16 lanes x J slots
         run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank);
-        return;
-#else
-        if constexpr (J == 2) {
-            // single-wave wide layout: half a wavefront per chain does everything
-            const int r = (blockIdx.x * kBlock + threadIdx.x) / kWide;
-            if (r >= n_hot) return;
-            const int begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
-            const int end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));
-            if (begin < end) run_hot_chain_wide(a, vals, begin, end, item_of_rank[r], threadIdx.x & (kWide - 1));
-            return;
-        }
-#endif
-        constexpr int T = HotTile<J>::value;
-        const int r = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
-        if (r >= n_hot) return;
-        const int begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
-        const int end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));  // r+1 <= item_mask
-        if (begin >= end) return;
-        const int y = item_of_rank[r];
-        Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
-        float ib = a.item_bias[y];
-        const int n_chunks = (end - begin) / kGroup;
-        int s = begin;
-        if (n_chunks > 0) {
-            const int last_chunk = begin + (n_chunks - 1) * kGroup;
-            RowTile<J, T> ra, rb;
-            ChunkMeta cur = load_meta(a, vals, s, lane);
-            load_rows<J, T>(ra, a, cur, 0, lane);
-            for (int c = 0; c < n_chunks; ++c) {
-                // next chunk's entries and biases: issued a whole chunk before they are needed
-                const ChunkMeta nxt = load_meta(a, vals, min(s + kGroup, last_chunk), lane);
-                float my_new_ub = 0.f;
-                if constexpr (T == 4) {
-                    load_rows<J, T>(rb, a, cur, 4, lane);
-                    run_rows<J, T>(ra, a, cur, 0, q, ib, my_new_ub, lane);
-                    load_rows<J, T>(ra, a, cur, 8, lane);
-                    run_rows<J, T>(rb, a, cur, 4, q, ib, my_new_ub, lane);
-                    load_rows<J, T>(rb, a, cur, 12, lane);
-                    run_rows<J, T>(ra, a, cur, 8, q, ib, my_new_ub, lane);
-                    load_rows<J, T>(ra, a, nxt, 0, lane);  // last chunk: a discarded re-load
-                    run_rows<J, T>(rb, a, cur, 12, q, ib, my_new_ub, lane);
-                } else {
-#pragma unroll
-                    for (int first = 0; first < kGroup; first += 2 * T) {
-                        load_rows<J, T>(rb, a, cur, first + T, lane);
-                        run_rows<J, T>(ra, a, cur, first, q, ib, my_new_ub, lane);
-                        if (first + 2 * T < kGroup) load_rows<J, T>(ra, a, cur, first + 2 * T, lane);
-                        else load_rows<J, T>(ra, a, nxt, 0, lane);
-                        run_rows<J, T>(rb, a, cur, first + T, q, ib, my_new_ub, lane);
-                    }
-                }
-                a.user_bias[static_cast<int>(cur.val >> 32)] = my_new_ub;  // 16 users, one store
-                cur = nxt;
-                s += kGroup;
-            }
-        }
-        for (; s < end; ++s) {  // fewer than 16 entries left
-            const uint64_t val = vals[s];
-            const int x = static_cast<int>(val >> 32);
-            Row<J> p = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
-            const float ub = a.user_bias[x];
-            const float new_ub = chain_step<J>(a, p, q, ub, ib, __uint_as_float(static_cast<uint32_t>(val)));
-            store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
-            if (lane == 0) a.user_bias[x] = new_ub;
-        }
-        store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
-        if (lane == 0) a.item_bias[y] = ib;
         return;
     }
     const int group = ((blockIdx.x - hot_blocks) * kBlock + threadIdx.x) / kGroup;
@@ -706,9 +446,7 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream) {
-    // hot blocks: the two-wave form holds DuoShape::kChains chains per block; the legacy forms one per lane group
-    const int chains_per_block = CU2REC_HOT_DUO ? DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains
-                                                 : (J == 2 ? kBlock / kWide : kGroupsPerBlock);
+    const int chains_per_block = DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains;
     const int hot_blocks = (n_hot + chains_per_block - 1) / chains_per_block;
     const int groups = (n_active + kWindow - 1) / kWindow;
     const int blocks = hot_blocks + (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
