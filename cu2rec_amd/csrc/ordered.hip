@@ -46,7 +46,7 @@ namespace {
 using namespace dev;
 
 constexpr int kWindow = 4;     // sorted positions per group (regular chains)
-constexpr int kHotChains = 256;  // most popular items: one group each, tile-prefetched (see sgd_ordered_kernel)
+constexpr int kHotChains = 256;  // most popular items: their chains run in the two-wave form (run_hot_block_duo)
 
 __global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__restrict__ indptr,
                                                                const int *__restrict__ indices,
@@ -394,9 +394,8 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
 }
 
 // One launch = one iteration.  Two roles, chosen per block:
-//  * blocks [0, hot_blocks): one group per popularity rank r < n_hot.  These are the long chains (thousands of
-//    updates on the most rated items); the chain is the critical path of the iteration, so its user rows are
-//    fetched a tile ahead (double buffered in registers) and only arithmetic stays on the dependent path.
+//  * blocks [0, hot_blocks): the chains of popularity ranks r < n_hot, DuoShape::kChains per block, in the two-wave
+//    form above.  These are the long chains (thousands of updates on the most rated items), i.e. the critical path.
 //  * the other blocks: a group owns a window of kWindow sorted positions and runs every chain of rank >= n_hot
 //    that STARTS in its window (chains are short there; one row of look-ahead).
 template <int J>
