@@ -245,20 +245,19 @@ __device__ __forceinline__ void duo_step_a(DuoLds<W, S> &l, int buf, int t, cons
     for (int s = 1; s < S; ++s) acc = acc + slot_dot(q.v[s], po.v[s]);
     const float dot = W == kWide ? row_sum16(cross_row_sum(acc)) : row_sum16(acc);  // canonical order either way
     const float err = rating - (((a.global_bias + ub) + ib) + dot);
+#if !(CU2REC_ABLATE & 16)
+#pragma unroll
+    for (int s = 0; s < S; ++s) l.qold[buf][t][s][lane] = q.v[s];
+    if (lane == 0) l.err[buf][t] = err;
+#endif
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const float4 qo = q.v[s];
-#if !(CU2REC_ABLATE & 16)
-        l.qold[buf][t][s][lane] = qo;
-#endif
         q.v[s].x = step(qo.x, po.v[s].x, err, a.h.lr, a.h.q_reg);
         q.v[s].y = step(qo.y, po.v[s].y, err, a.h.lr, a.h.q_reg);
         q.v[s].z = step(qo.z, po.v[s].z, err, a.h.lr, a.h.q_reg);
         q.v[s].w = step(qo.w, po.v[s].w, err, a.h.lr, a.h.q_reg);
     }
-#if !(CU2REC_ABLATE & 16)
-    if (lane == 0) l.err[buf][t] = err;
-#endif
     ib = ib + a.h.lr * (err - a.h.ib_reg * ib);
 }
 
