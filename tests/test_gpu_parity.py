@@ -577,3 +577,30 @@ def test_converged_run_matches_mf_sequential_within_1e4():
     log_s, (Ps, Qs, ubs, ibs), _ = logs["seq"]
     assert abs(float(losses[iters - 1]) - log_s[-1]["test_rmse"]) <= 1e-4
     assert np.abs(gP - Ps).max() <= 1e-3 and np.abs(gQ - Qs).max() <= 1e-3
+
+
+def test_netflix_shape_full_size_bit_exact():
+    """BASELINE.json configs[4] shape (480,189 users x 17,770 items, 79 M integer ratings, f=128 -- the largest
+    configuration): 3 ordered iterations and the fused loss against the sequential CPU oracle, every one of the
+    63.7 M parameters bit for bit; then Hogwild keeps everything finite and lowers the test RMSE."""
+    import bench
+    tr, te = bench.load_dataset("netflix", 20240917, 0, lambda: None)
+    assert tr.rows == 480189 and tr.cols == 17770 and tr.nnz > 70_000_000
+    f = 128
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    dtr, dte = cu.DeviceCSR(tr), cu.DeviceCSR(te)
+    model.sgd(dtr, HYPER, 42, 0, 3, mode="ordered")
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, 3, dot_order=orc.DOT_TREE16)
+    gP, gQ, gub, gib = model.download()
+    np.testing.assert_array_equal(gQ, Q)
+    np.testing.assert_array_equal(gP, P)
+    np.testing.assert_array_equal(gub, ub)
+    np.testing.assert_array_equal(gib, ib)
+    got = model.loss(dte)
+    want = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_TREE16)
+    assert got["rmse"] == want["rmse"] and got["mae"] == want["mae"]
+    assert abs(got["sum_sq"] - want["sum_sq"]) <= 1e-12 * want["sum_sq"]
+    model.sgd(dtr, HYPER, 42, 3, 200, mode="hogwild")
+    after = model.loss(dte)["rmse"]
+    assert np.isfinite(after) and after < got["rmse"]

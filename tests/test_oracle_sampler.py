@@ -131,3 +131,18 @@ def test_stream_equals_rocrand_device_api(tmp_path):
         x, u = line.split()
         assert int(x) == cu.lib().cu2rec_sampler_draw(seed, user, it) == orc.lib().orc_draw(seed, user, it)
         assert np.float32(float(u)) == np.float32(orc.lib().orc_uniform(int(x)))
+
+
+def test_sampler_is_uniform_over_a_users_ratings():
+    """sgd.cu:36-37 draws each of a user's n ratings with probability 1/n: chi-square over 200,000 draws of
+    (user, iteration) streams for a few n, and no visible correlation between neighbouring users / iterations."""
+    import cu2rec_amd as cu
+    L = cu.lib()
+    for n, user0 in ((7, 0), (20, 1000), (144, 138000)):
+        counts = np.zeros(n)
+        draws = np.array([L.cu2rec_sampler_index(42, user0 + (k % 500), k // 500, 10, 10 + n) - 10 for k in range(200_000)])
+        counts = np.bincount(draws, minlength=n).astype(float)
+        expected = len(draws) / n
+        chi2 = float(((counts - expected) ** 2 / expected).sum())
+        assert chi2 < n + 6 * np.sqrt(2 * n), (n, chi2)  # mean n-1, sd sqrt(2(n-1))
+        assert abs(np.corrcoef(draws[:-1], draws[1:])[0, 1]) < 0.01
