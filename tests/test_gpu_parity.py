@@ -600,7 +600,8 @@ def test_netflix_shape_full_size_bit_exact():
     got = model.loss(dte)
     want = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_TREE16)
     assert got["rmse"] == want["rmse"] and got["mae"] == want["mae"]
-    assert abs(got["sum_sq"] - want["sum_sq"]) <= 1e-12 * want["sum_sq"]
+    # 19.7 M double additions in a different order (per group, per block, blocks) than the oracle's single pass
+    assert abs(got["sum_sq"] - want["sum_sq"]) <= 1e-11 * want["sum_sq"]
     model.sgd(dtr, HYPER, 42, 3, 200, mode="hogwild")
     after = model.loss(dte)["rmse"]
     assert np.isfinite(after) and after < got["rmse"]
