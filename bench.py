@@ -74,6 +74,18 @@ def cpu_baseline(train, test, f, hyper, budget_s=12.0):
     port = {"value": users * iters / dt, "unit": "updates/s", "cores": 1, "kind": "port",
             "sample": "oracle/cu2rec_oracle.c (mf_sequential.cu:102-143 with the Philox sampler), full training set, "
                       "%d iterations, f=%d, gcc -O3 -ffp-contract=off" % (iters, f)}
+    # ---- the same port, Hogwild over users on all host cores (OpenMP) -- the strongest CPU form of this path
+    P, Q, ub, ib = orc.init_model(train.rows, train.cols, f)
+    threads = orc.sgd_iterations_parallel(o_tr, P, Q, ub, ib, train.global_bias, hyper, 42, 0, 2)
+    t0 = time.perf_counter()
+    it_par = 0
+    while time.perf_counter() - t0 < budget_s / 4:
+        orc.sgd_iterations_parallel(o_tr, P, Q, ub, ib, train.global_bias, hyper, 42, 2 + it_par, 10)
+        it_par += 10
+    dt = time.perf_counter() - t0
+    port["all_cores"] = {"value": users * it_par / dt, "unit": "updates/s", "cores": threads, "kind": "port",
+                         "sample": "same port, users of an iteration split over %d OpenMP threads racing on the item rows "
+                                   "(Hogwild on the host), %d iterations" % (threads, it_par)}
     # ---- the reference's own binary on a user subsample written as CSV
     exe = orc.ref_binary("mf_cpu")
     if exe:

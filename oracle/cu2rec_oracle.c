@@ -15,6 +15,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ================================================================== config */
 
@@ -295,6 +298,35 @@ void orc_sgd_iterations(const int *indptr, const int *indices, const float *data
         for (int x = 0; x < rows; ++x)     /* :104 */
             orc_sgd_one(indptr, indices, data, x, P, Q, user_bias, item_bias, global_bias, h, f, seed,
                         iter0 + (uint64_t)i, dot_order, update_items);
+}
+
+int orc_sgd_iterations_parallel(const int *indptr, const int *indices, const float *data, int rows,
+                                float *P, float *Q, float *user_bias, float *item_bias, float global_bias,
+                                const orc_hyper *h, int f, uint64_t seed, uint64_t iter0, int n_iters,
+                                int dot_order, int n_threads) {
+    int used = 1;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    for (int i = 0; i < n_iters; ++i) {
+#ifdef _OPENMP
+#pragma omp parallel
+        {
+#pragma omp single
+            used = omp_get_num_threads();
+#pragma omp for schedule(static)
+            for (int x = 0; x < rows; ++x)
+                orc_sgd_one(indptr, indices, data, x, P, Q, user_bias, item_bias, global_bias, h, f, seed,
+                            iter0 + (uint64_t)i, dot_order, 1);
+        }
+#else
+        (void)n_threads;
+        for (int x = 0; x < rows; ++x)
+            orc_sgd_one(indptr, indices, data, x, P, Q, user_bias, item_bias, global_bias, h, f, seed, iter0 + (uint64_t)i,
+                        dot_order, 1);
+#endif
+    }
+    return used;
 }
 
 /* ================================================================== loss */

@@ -191,6 +191,20 @@ def sgd_one(csr, x, P, Q, ub, ib, global_bias, hyper, seed, it, dot_order=DOT_SE
                   float(global_bias), C.byref(h), P.shape[1], seed, it, dot_order, 1 if update_items else 0)
 
 
+def sgd_iterations_parallel(csr, P, Q, ub, ib, global_bias, hyper, seed, iter0, n_iters, n_threads=0, dot_order=DOT_SEQ):
+    """CPU-baseline only: Hogwild over users on n_threads host threads (0 = all).  Returns the thread count used."""
+    L = lib()
+    if L.orc_sgd_iterations_parallel.argtypes is None:
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.orc_sgd_iterations_parallel.restype = C.c_int
+        L.orc_sgd_iterations_parallel.argtypes = [ip, ip, fp, C.c_int, fp, fp, fp, fp, C.c_float, C.POINTER(Hyper),
+                                                  C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]
+    h = Hyper(*[float(v) for v in hyper])
+    return L.orc_sgd_iterations_parallel(_i(csr.indptr), _i(csr.indices), _f(csr.data), csr.rows, _f(P), _f(Q), _f(ub),
+                                         _f(ib), float(global_bias), C.byref(h), P.shape[1], seed, iter0, n_iters,
+                                         dot_order, int(n_threads))
+
+
 def loss(csr, P, Q, ub, ib, global_bias, dot_order=DOT_SEQ, acc=ACC_F64, want_errors=False, rows=None):
     f = P.shape[1]
     rows = csr.rows if rows is None else rows
