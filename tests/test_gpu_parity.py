@@ -605,3 +605,55 @@ def test_netflix_shape_full_size_bit_exact():
     model.sgd(dtr, HYPER, 42, 3, 200, mode="hogwild")
     after = model.loss(dte)["rmse"]
     assert np.isfinite(after) and after < got["rmse"]
+
+
+def test_two_logical_shards_on_one_gpu_match_the_oracle():
+    """N logical shards emulated on one device.  Two user shards, each an Engine with its own
+    replica of the item side, ordered mode (deterministic), item deltas reconciled every 3 iterations with the
+    product's pack / apply kernels (the all-reduce itself replaced by a tensor add) -- against the same schedule run
+    by the CPU oracle with numpy doing the merge: every parameter bit for bit."""
+    import torch
+    from cu2rec_amd.engine import DeviceRatings, Engine
+    from cu2rec_amd.parallel import plan_users
+    tr, _ = _small_set(users=500, items=150, nnz=12000, seed=21)
+    f, n_shards, sync, total = 24, 2, 3, 9
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    b = plan_users(tr.rows, n_shards)
+    bounds = list(zip(b[:-1], b[1:]))
+    shards = [tr.slice_users(u0, u1) for u0, u1 in bounds]
+    engines = [Engine(u1 - u0, tr.cols, f, tr.global_bias, P[u0:u1], Q, ub[u0:u1], ib) for u0, u1 in bounds]
+    ratings = [DeviceRatings(s, engines[0].device) for s in shards]
+    for e in engines:
+        e.snapshot_items()
+    # oracle side: full-size arrays, each shard sees only its users' rows through a masked CSR
+    oP = [P.copy() for _ in bounds]
+    oub = [ub.copy() for _ in bounds]
+    oQ, oib = [Q.copy() for _ in bounds], [ib.copy() for _ in bounds]
+    Qb, ibb = Q.copy(), ib.copy()
+    masked = []
+    for u0, u1 in bounds:
+        ip = tr.indptr.copy()
+        ip[:u0 + 1] = tr.indptr[u0]
+        ip[u1:] = tr.indptr[u1]
+        masked.append(orc.CSR(ip, tr.indices, tr.data, tr.rows, tr.cols))
+    for it in range(0, total, sync):
+        for k, (u0, _) in enumerate(bounds):
+            engines[k].sgd(ratings[k], HYPER, 42, it, sync, mode="ordered", user_offset=u0)
+            orc.sgd_iterations(masked[k], oP[k], oQ[k], oub[k], oib[k], tr.global_bias, HYPER, 42, it, sync,
+                               dot_order=orc.DOT_TREE16)
+        bufs = [e.pack_item_delta().clone() for e in engines]
+        total_buf = bufs[0] + bufs[1]  # what the all-reduce would deliver
+        for e in engines:
+            e.exchange.copy_(total_buf)
+            e.apply_item_delta(0.5)
+        dQ = (oQ[0] - Qb) + (oQ[1] - Qb)
+        dib = (oib[0] - ibb) + (oib[1] - ibb)
+        Qb, ibb = Qb + np.float32(0.5) * dQ, ibb + np.float32(0.5) * dib
+        for k in range(n_shards):
+            oQ[k], oib[k] = Qb.copy(), ibb.copy()
+    for k, (u0, u1) in enumerate(bounds):
+        gP, gQ, gub, gib = engines[k].download()
+        np.testing.assert_array_equal(gP, oP[k][u0:u1])
+        np.testing.assert_array_equal(gub, oub[k][u0:u1])
+        np.testing.assert_array_equal(gQ, Qb)
+        np.testing.assert_array_equal(gib, ibb)
