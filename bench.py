@@ -114,13 +114,12 @@ def cpu_baseline(train, test, f, hyper, budget_s=12.0):
     return out
 
 
-def measured_traffic(workload, f, mode):
+def measured_traffic(workload, f, name):
     """HBM bytes per launch of the SGD kernel from the committed rocprofv3 PMC passes (profiles/), priced as
     MI355X_MICROARCH.md prescribes (separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE doubled on
     gfx950).  Counters cannot be read from inside this process, so the figure is the latest committed one for
     this exact workload / kernel; None if there is none."""
     import glob
-    name = {"hogwild": "sgd_hogwild_kernel", "ordered": "sgd_ordered_kernel", "serial": "sgd_serial_kernel"}[mode]
     tag = "%s_f%d" % (workload.replace("-", ""), f)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % tag)), reverse=True):
         try:
@@ -206,6 +205,8 @@ def main():
     from cu2rec_amd.parallel import ShardedSGD
 
     log("torch + library loaded, device %s" % torch.cuda.get_device_name(device))
+    if world > 1 and backend != "nccl":
+        cu.lib().cu2rec_hogwild_resident(0)  # ranks share a GPU here: a resident launch needs the GPU to itself
     train, test = load_dataset(args.workload, args.seed, rank, barrier)
     log("dataset ready: %d users, %d items, %d train ratings" % (train.rows, train.cols, train.nnz))
     f = args.factors
@@ -250,20 +251,52 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- SGD kernel duration: HIP events around single launches on the launch stream (untimed extra pass)
-    n_s = max(args.kernel_samples, 1)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_s)]
-    k_launch = max(args.iters_per_launch, 1) if args.mode == "hogwild" else 1  # iterations covered by one launch
-    for a, b in evs:
-        a.record()
-        eng.sgd(d_train, hyper, 42, it, k_launch, mode, True, user_offset)
-        b.record()
-        it += k_launch
-    torch.cuda.synchronize()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    kernel_ms_min = float(np.min([a.elapsed_time(b) for a, b in evs]))
+    # ---- SGD kernel duration: HIP events around single launches on the launch stream (untimed extra pass).
+    # Hogwild calls of `sync_every` iterations are ONE resident launch when the user rows fit the register file
+    # (cu2rec_amd/csrc/resident.hip); otherwise a launch is one iteration (or --iters-per-launch of them).
+    import ctypes
+    blocks_c, upg_c = ctypes.c_int(0), ctypes.c_int(0)
+    resident = (args.mode == "hogwild" and args.iters_per_launch == 1 and
+                cu.lib().cu2rec_hogwild_resident_plan(train.rows, f, sync_every, ctypes.byref(blocks_c), ctypes.byref(upg_c)) == 1)
+    kernel_name = "sgd_resident_kernel" if resident else "sgd_%s_kernel" % args.mode
+    k_launch = sync_every if resident else (max(args.iters_per_launch, 1) if args.mode == "hogwild" else 1)
+    n_s = max(args.kernel_samples // (8 if resident else 1), 1)
 
-    log("kernel avg %.2f us (min %.2f us)" % (1e3 * kernel_ms, 1e3 * kernel_ms_min))
+    def time_launches(n_samples, iters_per_launch, start_it):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_samples)]
+        for a, b in evs:
+            a.record()
+            eng.sgd(d_train, hyper, 42, start_it, iters_per_launch, mode, True, user_offset)
+            b.record()
+            start_it += iters_per_launch
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in evs]
+        return float(np.mean(ms)), float(np.min(ms)), start_it
+
+    kernel_ms, kernel_ms_min, it = time_launches(n_s, k_launch, it)
+    log("%s: %d iteration(s) per launch, avg %.2f us (min %.2f us) per launch" % (kernel_name, k_launch, 1e3 * kernel_ms,
+                                                                                   1e3 * kernel_ms_min))
+    # ---- the streaming form beside it (one launch per iteration, user rows through HBM): same data, same model
+    streaming = None
+    if resident:
+        prev = cu.lib().cu2rec_hogwild_resident(0)
+        try:
+            s_ms, s_min, it = time_launches(max(args.kernel_samples, 1), 1, it)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.sgd(d_train, hyper, 42, it, 500, mode, True, user_offset)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            it += 500
+        finally:
+            cu.lib().cu2rec_hogwild_resident(prev)
+        s_bytes = users_active * (16 * f + 32)
+        streaming = {"mode": "hogwild, one launch per iteration (CU2REC_RESIDENT=0): user rows stream through HBM",
+                     "kernel": "sgd_hogwild_kernel", "value": users_active * 500 / dt, "unit": "updates/s",
+                     "ms_per_step": 1e3 * dt / 500, "steps": 500, "kernel_avg_us": 1e3 * s_ms, "kernel_min_us": 1e3 * s_min,
+                     "algorithmic_bytes_per_launch": s_bytes, "achieved_GBs": s_bytes / (s_ms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        log("streaming kernel: avg %.2f us per launch, %.4f ms/step" % (1e3 * s_ms, streaming["ms_per_step"]))
     final = job.loss(d_test)
     final_iterations = it
 
@@ -342,15 +375,23 @@ def main():
             "test_rmse": final["rmse"], "test_rmse_initial": rmse0, "iterations_run": final_iterations,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sgd_%s_kernel" % args.mode, "kernel_avg_us": 1e3 * kernel_ms,
+                         "kernel": kernel_name, "kernel_avg_us": 1e3 * kernel_ms,
                          "kernel_min_us": 1e3 * kernel_ms_min, "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_update": bytes_per_update},
+                         "bytes_per_update": bytes_per_update, "iterations_per_launch": k_launch},
         }
-        traffic = measured_traffic(args.workload, f, args.mode)
+        if resident:
+            line["roofline"]["note"] = (
+                "one persistent launch = %d iterations; %d workgroups x 32 groups keep %d user rows each in registers, so "
+                "the 8f bytes per update of user-row traffic in the algorithmic count never reach HBM: frac > 1 means the "
+                "kernel beats the roofline of the streaming formulation, `traffic` is what HBM really moved"
+                % (k_launch, blocks_c.value, upg_c.value))
+        traffic = measured_traffic(args.workload, f, kernel_name)
         if traffic:
             line["roofline"]["traffic"] = traffic["bytes_per_launch"]
             line["roofline"]["traffic_source"] = traffic["source"]
         line["loss_kernel"] = loss_kernel
+        if streaming:
+            line["hogwild_streaming_mode"] = streaming
         if ordered:
             line["ordered_mode"] = ordered
         if blocked:

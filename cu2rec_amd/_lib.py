@@ -75,6 +75,8 @@ SIGNATURES = {
     "cu2rec_sgd_update": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,
                                     C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "cu2rec_hogwild_iters_per_launch": (C.c_int, [C.c_int]),
+    "cu2rec_hogwild_resident": (C.c_int, [C.c_int]),
+    "cu2rec_hogwild_resident_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cu2rec_schedule_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "cu2rec_schedule_destroy": (None, [_P]),
     "cu2rec_sgd_update_ordered": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,

@@ -10,6 +10,7 @@
 #include "device.hpp"
 #include "hip_check.hpp"
 #include "kernels.hpp"
+#include "resident.hpp"
 
 namespace cu2rec {
 
@@ -92,6 +93,7 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
                               n_factors, hyper, seed, update_items, user_offset);
     if (n_rows == 0 || n_iters == 0) return;
     require_device();
+    resident_check_fault();
     if (mode == CU2REC_SGD_SERIAL) {
         // one launch walks all iterations in order
         a.iter0 = iter0;
@@ -101,6 +103,9 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
         // one launch per reference iteration (training.cu:107-113): the kernel boundary is the
         // point where every user's update of iteration i is visible to iteration i+1
         const int block = std::max(1, g_hogwild_block.load());
+        // the same iterations in ONE persistent launch (grid barrier where the kernel boundary was, user rows
+        // resident in registers) whenever the rows fit and the policy allows it: resident.hip
+        if (block == 1 && resident_launch(a, iter0, n_iters, stream)) return;
         for (int i = 0; i < n_iters; i += block) {
             a.iter0 = iter0 + static_cast<uint64_t>(i);
             a.iters = std::min(block, n_iters - i);
@@ -144,6 +149,7 @@ void loss(const int *indptr, const int *indices, const float *data, int n_rows, 
         check_aligned(P, "P");
         check_aligned(Q, "Q");
         require_device();
+        resident_check_fault();
         LossArgs a{};
         a.indptr = indptr;
         a.indices = indices;
@@ -164,6 +170,7 @@ void loss(const int *indptr, const int *indices, const float *data, int n_rows, 
         launch_loss(a, blocks, stream);
         CU2REC_HIP(hipGetLastError());
         s = collect_partials(a.partials, blocks, stream);
+        resident_check_fault();  // the stream has been drained: a resident launch before this pass has reported by now
     }
     if (sum_abs) *sum_abs = s.sum_abs;
     if (sum_sq) *sum_sq = s.sum_sq;
@@ -258,6 +265,7 @@ DeviceModel::DeviceModel(int rows_, int cols_, int f_, const float *hP, const fl
 
 void DeviceModel::download(float *hP, float *hQ, float *hub, float *hib) const {
     CU2REC_HIP(hipDeviceSynchronize());
+    resident_check_fault();
     if (hP) download_padded(P, hP, rows, n_factors, ld);
     if (hQ) download_padded(Q, hQ, cols, n_factors, ld);
     if (hub && rows) user_bias.download(hub, rows);
@@ -348,6 +356,18 @@ int cu2rec_hogwild_iters_per_launch(int k) {
     const int prev = g_hogwild_block.load();
     if (k >= 1) g_hogwild_block.store(k);
     return prev;
+}
+
+int cu2rec_hogwild_resident(int policy) { return resident_policy(policy); }
+
+int cu2rec_hogwild_resident_plan(int n_rows, int n_factors, int n_iters, int *blocks, int *users_per_group) {
+    int yes = 0;
+    const int rc = guarded([&] {
+        require(n_rows >= 0 && n_factors > 0, "cu2rec_hogwild_resident_plan: bad shape");
+        require_device();
+        yes = resident_plan(n_rows, n_factors, n_iters, blocks, users_per_group) ? 1 : 0;
+    });
+    return rc == CU2REC_OK ? yes : rc;
 }
 
 int cu2rec_schedule_create(const int *indptr, const int *indices, int n_rows, int n_cols, int nnz,

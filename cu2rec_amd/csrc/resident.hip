@@ -1,0 +1,537 @@
+// Resident Hogwild SGD for gfx950: the reference's per-iteration launches (training.cu:107-113, sgd_update
+// sgd.cu:22-75) folded into ONE persistent launch that keeps every user's factor row in the register file.
+//
+// Why: in the streaming kernel (kernels.hip, sgd_hogwild_kernel) half of the 16 f + 32 algorithmic bytes per
+// update are the user's own row going to HBM and back between two launches, although nobody else ever
+// touches it.  An MI355X has 256 CUs x 512 KB of vector registers = 128 MB -- more than the whole P matrix
+// of the ML-20M shape (55 MB).  So: one 512-thread workgroup per CU, each 16-lane group owns R = ceil(U / G)
+// users (G = groups in the grid), loads their rows ONCE, runs all iterations of the launch on them and
+// stores them once at the end.  Per iteration only the item side moves: sample -> item id / rating
+// (CSR gather) -> item row read, rank-1 update, item row write.
+//
+// Semantics are those of one launch per iteration: between two iterations sits a grid-wide barrier with an
+// agent-scope release (every item row written in iteration i has left the XCD's L2) and acquire (the CU's L1
+// is invalidated), so iteration i + 1 reads what iteration i wrote, on every XCD -- exactly what the kernel
+// boundary gives the streaming form.  Inside an iteration it is Hogwild as before (sgd.cu:18-21): all users in
+// flight, two users that sampled the same item both read the row as it was, the later store wins.
+//
+// Layout inside a group (lanes 0..15 = one DPP row, as everywhere else):
+//   p[r]          Row<J> of the group's r-th user, r < RMAX, in registers for the whole launch
+//   my_*[m]       per-user scalars (row start, row length, user bias, this iteration's sample) are
+//                 LANE-distributed: lane l of set m holds them for user r = 16 m + l, so ONE Philox pass and
+//                 ONE gather per set serve 16 users; a 16-wide shuffle hands them to the group when user r
+//                 is processed.
+// The update loop is software pipelined by hand: the item rows of D users are in flight while one is computed.
+// The arithmetic of an update is the shared device code of sgd_device.hpp, bit for bit.
+//
+// The grid barrier follows MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility" and
+// its XCD-hierarchical form ("barrier-xcd"): every wave drains its stores, workgroup barrier, lane 0 arrives on its
+// XCD's counter; the last arriver of an XCD does the ONE agent-scope release for that XCD's L2, reports to the top
+// counter, waits for all XCDs and opens the XCD's generation word, which the other workgroups poll (relaxed sc1
+// loads with s_sleep); everybody ends with an agent acquire fence, drained, workgroup barrier.  (A flat barrier
+// with one release per workgroup cost 28 us per iteration here: 32 L2 write-backs per XCD queue behind each other.)
+// The barrier is split in two halves and the next iteration's sample gathers sit between them.  Every spin is
+// bounded (wall clock): a grid that is not co-resident ends with the status word set instead of hanging, and the
+// host reports it (resident_check_fault).  Residency comes from the grid size alone: at most one workgroup per CU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+#include "hip_check.hpp"
+#include "kernels.hpp"
+#include "resident.hpp"
+#include "sampler.hpp"
+#include "sgd_device.hpp"
+
+#ifndef CU2REC_RES_ABLATE
+#define CU2REC_RES_ABLATE 0  // timing-only builds (tools/build_variant.sh), bits: 1 no grid barrier, 2 no updates, 4 no item-row
+                             // stores, 8 no item-row loads; never set in the shipped library
+#endif
+
+#ifndef CU2REC_RES_D2
+#define CU2REC_RES_D2 3  // item rows in flight per group at two float4 per lane (f = 68..128)
+#endif
+
+namespace cu2rec {
+
+namespace {
+
+using namespace dev;
+
+constexpr int kResBlock = 512;                    // 8 wavefronts = 2 per SIMD: up to 256 VGPRs each
+constexpr int kResGroups = kResBlock / kGroup;    // 32 user groups per workgroup
+constexpr unsigned long long kBarrierTimeoutTicks = 300000000ull;  // 3 s of the 100 MHz wall clock
+
+// Barrier words, each on a 128-byte line of its own (indices into an array of unsigned, zeroed before every launch):
+constexpr int kLine = 32;
+constexpr int kMaxXcc = 16;
+constexpr int kWTop = 0;                                  // XCD leaders that have released, summed over phases
+constexpr int kWCensusTop = kLine;                        // workgroups that have reported their XCD
+constexpr int kWCensus = 2 * kLine;                       // [x]: workgroups on XCD x
+constexpr int kWArrive = kWCensus + kMaxXcc * kLine;      // [x]: arrivals on XCD x, summed over phases
+constexpr int kWGen = kWArrive + kMaxXcc * kLine;         // [x]: last phase XCD x may leave
+constexpr int kBarrierWords = kWGen + kMaxXcc * kLine;
+
+struct ResidentArgs {
+    unsigned *words;       // the barrier block above (device memory)
+    unsigned *status;      // set to 1 by a workgroup that gave up waiting (sticky; the host reads it)
+    float *sink;           // kSinkFloats floats nobody reads: where the updates of users without ratings are written
+    int users_per_group;   // R
+};
+constexpr int kSinkBias = 512;                 // sink[0 .. 511]: an item row, sink[512]: an item bias
+constexpr int kSinkFloats = kSinkBias + 16;
+
+struct BarrierShared {  // per workgroup, in LDS; written by thread 0 only
+    int xcc, n_mine, n_xcds, leader, ok;
+};
+
+__device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load sc1: never L1-served
+}
+
+// Spins until *p - target >= 0 (wrap-safe); false if the status word is set or 3 s have passed (then sets it).
+__device__ __forceinline__ bool spin_until(const unsigned *p, unsigned target, unsigned *status) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned polls = 0;
+    while (static_cast<int>(ld_relaxed(p) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 63u) == 0 && (ld_relaxed(status) != 0 || wall_clock64() - t0 > kBarrierTimeoutTicks)) {
+            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+    }
+    return true;
+}
+
+// Once per launch, thread 0 of every workgroup: which XCD am I on, how many workgroups share it, how many XCDs
+// are in use.  (Placement is the dispatcher's business; the barrier only needs the counts.)
+__device__ __forceinline__ void barrier_census(const ResidentArgs &ra, BarrierShared *bs) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= kMaxXcc - 1;
+    __hip_atomic_fetch_add(ra.words + kWCensus + xcc * kLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ra.words + kWCensusTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bs->ok = spin_until(ra.words + kWCensusTop, gridDim.x, ra.status) ? 1 : 0;
+    int n_xcds = 0;
+    for (int x = 0; x < kMaxXcc; ++x) n_xcds += ld_relaxed(ra.words + kWCensus + x * kLine) != 0;
+    bs->xcc = static_cast<int>(xcc);
+    bs->n_mine = static_cast<int>(ld_relaxed(ra.words + kWCensus + xcc * kLine));
+    bs->n_xcds = n_xcds;
+}
+
+// Grid barrier, split in two so that work which does not depend on other workgroups (the next iteration's sample
+// gathers) runs while the chip drains.  XCD-hierarchical: the LAST workgroup to arrive on an XCD is its leader and
+// does the one agent-scope release (L2 write-back) for that XCD -- every other workgroup of the XCD has drained its
+// stores into that same L2 before it arrived -- then reports to the top counter, waits for all XCDs and opens its
+// XCD's generation word; the others only poll that word.  Everybody ends with an agent-scope acquire (L1 invalidate).
+__device__ __forceinline__ void barrier_arrive(const ResidentArgs &ra, unsigned phase, BarrierShared *bs) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's item-row stores have reached L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ra.words + kWArrive + bs->xcc * kLine, 1u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+        const bool leader = old + 1 == phase * static_cast<unsigned>(bs->n_mine);
+        if (leader) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the compiler may drop its own wait here)
+            __hip_atomic_fetch_add(ra.words + kWTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bs->leader = leader ? 1 : 0;
+    }
+}
+
+// true: everybody arrived.  false: gave up (status word set); the caller leaves its iteration loop.
+__device__ __forceinline__ bool barrier_wait(const ResidentArgs &ra, unsigned phase, BarrierShared *bs) {
+    if (threadIdx.x == 0) {
+        bool ok;
+        unsigned *gen = ra.words + kWGen + bs->xcc * kLine;
+        if (bs->leader) {
+            ok = spin_until(ra.words + kWTop, phase * static_cast<unsigned>(bs->n_xcds), ra.status);
+            __hip_atomic_store(gen, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            ok = spin_until(gen, phase, ra.status);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // invalidate this CU's L1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and wait until it has happened
+        bs->ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return bs->ok != 0;
+}
+
+// A lane's float4 slots of a row, "wrapped": where lane + 16 j runs past the row (f = 100: the second slot of lanes
+// 9..15) the lane holds a DUPLICATE of a real slot instead of padding.  Duplicates are loaded from, updated like
+// and stored to the slot they copy -- same inputs, same operations, same bits, so the extra store is the same bytes
+// to the same address in the same instruction -- and are masked out of the dot product, where they contribute the
+// +0.0 the zero padding of the streaming layout contributes.  That keeps every load and store of the update loop
+// unconditional: no exec-masked memory operation, hence no branch, hence exact s_waitcnt counts (see below).
+template <int J>
+struct Slots {
+    int off[J];       // float4 index inside a row
+    bool last_valid;  // does slot lane + 16 (J - 1) exist?  (all earlier ones do)
+};
+
+template <int J>
+__device__ __forceinline__ Row<J> load_wrapped(const float *row, const Slots<J> &sl) {
+    const float4 *p4 = reinterpret_cast<const float4 *>(row);
+    Row<J> r;
+#pragma unroll
+    for (int j = 0; j < J; ++j) r.v[j] = p4[sl.off[j]];
+    return r;
+}
+
+template <int J>
+__device__ __forceinline__ void store_wrapped(float *row, const Slots<J> &sl, const Row<J> &r) {
+    float4 *p4 = reinterpret_cast<float4 *>(row);
+#pragma unroll
+    for (int j = 0; j < J; ++j) p4[sl.off[j]] = r.v[j];
+}
+
+// predict<J> (sgd_device.hpp) on wrapped rows: same operations in the same order, the duplicate slot counts as +0.0
+template <int J>
+__device__ __forceinline__ float predict_wrapped(const Row<J> &p, const Row<J> &q, float ub, float ib, float gb,
+                                                 bool last_valid) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        float sd = slot_dot(q.v[j], p.v[j]);
+        if (j == J - 1) sd = last_valid ? sd : 0.f;
+        acc = j == 0 ? sd : acc + sd;
+    }
+    const float dot = row_sum16(acc);
+    return ((gb + ub) + ib) + dot;
+}
+
+// R (users per group) is a compile-time parameter and the whole update loop is straight-line code, because the
+// compiler's s_waitcnt insertion counts outstanding memory operations conservatively across every branch: with a
+// run-time `r < R`, an exec-masked load / store or an `if (update_items)` anywhere in the loop, each step ended up
+// waiting for everything in flight (vmcnt(0)) -- no software pipelining at all (measured: D = 1..5 all took 19 us
+// per iteration); early exits out of an unrolled chain made the register allocator spill hundreds of registers
+// instead.  So: a few R per row width are compiled, the host rounds the count it needs up to the next one and
+// shrinks the grid to match; frozen items (update_items == 0) take the streaming kernel, which needs no barrier.
+template <int J, int RMAX, int D>
+__global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, ResidentArgs ra) {
+    constexpr bool UPD = true;
+    constexpr int R = RMAX;
+    static_assert(D >= 1 && D <= RMAX, "pipeline depth");
+    constexpr int M = (RMAX + kGroup - 1) / kGroup;  // lane-distributed scalar sets
+    __shared__ BarrierShared s_barrier;
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = blockIdx.x * kResGroups + (threadIdx.x / kGroup);
+    const int n_groups = gridDim.x * kResGroups;
+
+    Slots<J> sl;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int slot = lane + kGroup * j;
+        sl.off[j] = slot < a.nslots ? slot : lane % a.nslots;
+    }
+    sl.last_valid = lane + kGroup * (J - 1) < a.nslots;
+
+    // ---- prologue: the group's users move in -------------------------------------------------------
+    int my_x[M], my_low[M], my_n[M];
+    float my_ub[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const int r = m * kGroup + lane;
+        const int x = group + r * n_groups;  // user r of the group; consecutive groups own consecutive users
+        const bool valid = r < R && x < a.n_rows;
+        my_x[m] = x;
+        my_low[m] = valid ? a.indptr[x] : 0;
+        my_n[m] = valid ? a.indptr[x + 1] - my_low[m] : 0;  // 0: no ratings, skipped (sgd.cu:34)
+        my_ub[m] = valid ? a.user_bias[x] : 0.f;
+    }
+    Row<J> p[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        const int x = group + r * n_groups;
+        if (r < R && x < a.n_rows) {
+            p[r] = load_wrapped<J>(a.P + static_cast<size_t>(x) * a.ldp, sl);
+        } else {
+#pragma unroll
+            for (int j = 0; j < J; ++j) p[r].v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    // sample of iteration `it` for the 16 users of every set: one draw + one gather per lane (sgd.cu:36-44)
+    auto draw = [&](uint64_t it, int (&item)[M], float (&rating)[M]) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            item[m] = 0;
+            rating[m] = 0.f;
+            if (my_n[m] > 0) {
+                const int y_i = sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + my_x[m]), it, my_low[m],
+                                              my_low[m] + my_n[m]);
+                item[m] = a.indices[y_i];
+                rating[m] = a.data[y_i];
+            }
+        }
+    };
+
+    int item[M];
+    float rating[M];
+    draw(a.iter0, item, rating);
+    const bool synced = !(CU2REC_RES_ABLATE & 1) && UPD && a.iters > 1;  // frozen items: nothing crosses users
+    bool alive = true;
+    if (synced) {
+        if (threadIdx.x == 0) barrier_census(ra, &s_barrier);
+        __syncthreads();
+        alive = s_barrier.ok != 0;  // false: the grid is not co-resident; nothing is run, the host reports it
+    }
+
+    // ---- the iterations ----------------------------------------------------------------------------
+    // One step = "compute the user whose item row was requested D steps ago, then request the next user's".  The
+    // step bodies contain no branch: users without ratings and the unused slots of the last, partly filled row of
+    // the user -> group assignment read item row 0 and write to a sink row.
+    Row<J> q[D];
+    float q_ib[D], q_rating[D];
+    int q_item[D];
+    bool q_active[D];
+
+    const int64_t sink_row_off = reinterpret_cast<char *>(ra.sink) - reinterpret_cast<char *>(a.Q);
+    const int64_t sink_bias_off = reinterpret_cast<char *>(ra.sink + kSinkBias) - reinterpret_cast<char *>(a.item_bias);
+
+    auto issue = [&](int r, int s) {  // r, s: constants after unrolling
+        const int set = r / kGroup, src = r % kGroup;
+        q_item[s] = __shfl(item[set], src, kGroup);  // 0 for a user without ratings
+        q_rating[s] = __shfl(rating[set], src, kGroup);
+        q_active[s] = __shfl(my_n[set], src, kGroup) > 0;
+        if (!(CU2REC_RES_ABLATE & 8)) {
+            q[s] = load_wrapped<J>(a.Q + static_cast<size_t>(q_item[s]) * a.ldq, sl);
+            q_ib[s] = a.item_bias[q_item[s]];
+        } else {
+            q[s] = p[0];
+            q_ib[s] = 0.f;
+        }
+    };
+    auto consume = [&](Row<J> &pc, int c, int s) {
+        const int set = c / kGroup, src = c % kGroup;
+        const float ub = __shfl(my_ub[set], src, kGroup);
+        const float ib = q_ib[s];
+        const float err = q_rating[s] - predict_wrapped<J>(pc, q[s], ub, ib, a.global_bias, sl.last_valid);  // sgd.cu:45
+        rank1_update<J>(pc, q[s], err, a.h);                                                                // sgd.cu:53-64
+        // the new user row is not needed before the next iteration, and left alone the optimizer sinks its computation
+        // to the end of the loop, keeping err * q (4 J registers) alive per user until then: pin it to this step
+#pragma unroll
+        for (int j = 0; j < J; ++j) asm volatile("" : "+v"(pc.v[j].x), "+v"(pc.v[j].y), "+v"(pc.v[j].z), "+v"(pc.v[j].w));
+        if (UPD && !(CU2REC_RES_ABLATE & 4)) {                                                              // sgd.cu:61,70
+            // the sink is addressed as a byte offset from Q / item_bias so that "real row or sink" is a select
+            // between two integers (a select between two pointers comes back as a branch around the stores)
+            const int64_t row_off = q_active[s] ? static_cast<int64_t>(q_item[s]) * a.ldq * 4 : sink_row_off;
+            store_wrapped<J>(reinterpret_cast<float *>(reinterpret_cast<char *>(a.Q) + row_off), sl, q[s]);
+            // all 16 lanes store the same value to the same address: one request, and no lane == 0 branch
+            const int64_t bias_off = q_active[s] ? static_cast<int64_t>(q_item[s]) * 4 : sink_bias_off;
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(a.item_bias) + bias_off) =
+                ib + a.h.lr * (err - a.h.ib_reg * ib);  // sgd.cu:71
+        }
+        const float ub_new = ub + a.h.lr * (err - a.h.ub_reg * ub);  // sgd.cu:67
+        my_ub[set] = (lane == src && q_active[s]) ? ub_new : my_ub[set];
+    };
+
+    for (int k = 0; alive && k < a.iters; ++k) {
+        // make the compiler wait for this iteration's samples HERE, before any item row is in flight (an operand use
+        // is what its s_waitcnt insertion sees; later it could only wait for them together with the rows)
+#pragma unroll
+        for (int m = 0; m < M; ++m) asm volatile("" ::"v"(item[m]), "v"(rating[m]));
+
+        if (!(CU2REC_RES_ABLATE & 2)) {
+#pragma unroll
+            for (int r = 0; r < R + D; ++r) {
+                if (r >= D) consume(p[r - D], r - D, (r - D) % D);
+                if (r < R) issue(r, r % D);
+                // keep a step's shuffles and address arithmetic inside the step: hoisted to the top of the
+                // straight-line code they cost ~10 live registers per user, which the resident rows need
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (k + 1 == a.iters) break;
+        // The sampler is value independent, so the next iteration's draws and CSR gathers need nothing from other
+        // workgroups: they run between the two halves of the barrier, while the XCDs write back and arrive.
+        const unsigned phase = static_cast<unsigned>(k) + 1;
+        if (synced) barrier_arrive(ra, phase, &s_barrier);
+        draw(a.iter0 + static_cast<uint64_t>(k) + 1, item, rating);
+        if (synced && !barrier_wait(ra, phase, &s_barrier)) break;
+    }
+
+    // ---- epilogue: the users move out (a user without ratings was never changed and is not written) ----
+    // The base pointer is made opaque so that the row addresses are computed again here: as common subexpressions of
+    // the prologue's they would stay in registers (4 J per user) for the whole launch.
+    float *P_out = a.P;
+    asm volatile("" : "+s"(P_out));
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        const int x = group + r * n_groups;
+        const bool has_ratings = __shfl(my_n[r / kGroup], r % kGroup, kGroup) > 0;
+        if (r < R && x < a.n_rows && has_ratings) store_wrapped<J>(P_out + static_cast<size_t>(x) * a.ldp, sl, p[r]);
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+        if (my_n[m] > 0) a.user_bias[my_x[m]] = my_ub[m];
+}
+
+// ---- host side --------------------------------------------------------------------------------------
+
+// Compiled (J, R) variants.  J = float4 slots per lane (row width), R = users per group: what fits 256 VGPRs without
+// spilling (f <= 64: 262,000 users; f <= 128: 147,000; f <= 192: 65,000; f <= 256: 49,000 on 256 CUs).
+struct Variant {
+    int j, r;
+    const void *kernel;
+};
+#define CU2REC_RES_VARIANT(J, R, D) {J, R, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D>)}
+const Variant kVariants[] = {
+    CU2REC_RES_VARIANT(1, 4, 4),   CU2REC_RES_VARIANT(1, 8, 4),   CU2REC_RES_VARIANT(1, 12, 4),  CU2REC_RES_VARIANT(1, 16, 4),
+    CU2REC_RES_VARIANT(1, 20, 4),  CU2REC_RES_VARIANT(1, 24, 4),  CU2REC_RES_VARIANT(1, 28, 4),  CU2REC_RES_VARIANT(1, 32, 4),
+    CU2REC_RES_VARIANT(2, 4, CU2REC_RES_D2),  CU2REC_RES_VARIANT(2, 6, CU2REC_RES_D2),  CU2REC_RES_VARIANT(2, 8, CU2REC_RES_D2),
+    CU2REC_RES_VARIANT(2, 10, CU2REC_RES_D2), CU2REC_RES_VARIANT(2, 12, CU2REC_RES_D2), CU2REC_RES_VARIANT(2, 14, CU2REC_RES_D2),
+    CU2REC_RES_VARIANT(2, 16, CU2REC_RES_D2), CU2REC_RES_VARIANT(2, 17, CU2REC_RES_D2), CU2REC_RES_VARIANT(2, 18, CU2REC_RES_D2),
+    CU2REC_RES_VARIANT(3, 4, 3),   CU2REC_RES_VARIANT(3, 6, 3),   CU2REC_RES_VARIANT(3, 8, 3),
+    CU2REC_RES_VARIANT(4, 4, 2),   CU2REC_RES_VARIANT(4, 6, 2),
+};
+#undef CU2REC_RES_VARIANT
+constexpr int kNumVariants = static_cast<int>(sizeof(kVariants) / sizeof(kVariants[0]));
+
+// smallest compiled variant with this J and at least `need` users per group; -1 if none
+int variant_for(int j, int need) {
+    int best = -1;
+    for (int i = 0; i < kNumVariants; ++i)
+        if (kVariants[i].j == j && kVariants[i].r >= need && (best < 0 || kVariants[i].r < kVariants[best].r)) best = i;
+    return best;
+}
+
+struct DeviceState {
+    bool ready = false;
+    bool usable[kNumVariants] = {};   // the occupancy query admits one workgroup per CU
+    int cus = 0;
+    unsigned *words = nullptr;        // device: the barrier block (kBarrierWords), then the status word
+    float *sink = nullptr;            // device: kSinkFloats floats
+    unsigned *host_status = nullptr;  // pinned host copy of the status word, refreshed after every launch
+    hipEvent_t done = nullptr;        // end of the latest resident launch
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+};
+
+std::mutex g_mutex;
+std::vector<DeviceState> g_states;
+std::atomic<int> g_policy{-1};
+
+DeviceState &state_for_current_device() {
+    int dev = 0;
+    CU2REC_HIP(hipGetDevice(&dev));
+    if (static_cast<int>(g_states.size()) <= dev) g_states.resize(dev + 1);
+    DeviceState &s = g_states[dev];
+    if (!s.ready) {
+        hipDeviceProp_t prop;
+        CU2REC_HIP(hipGetDeviceProperties(&prop, dev));
+        s.cus = prop.multiProcessorCount;
+        CU2REC_HIP(hipMalloc(reinterpret_cast<void **>(&s.words), (kBarrierWords + kLine) * sizeof(unsigned)));
+        CU2REC_HIP(hipMemset(s.words, 0, (kBarrierWords + kLine) * sizeof(unsigned)));
+        CU2REC_HIP(hipMalloc(reinterpret_cast<void **>(&s.sink), kSinkFloats * sizeof(float)));
+        CU2REC_HIP(hipMemset(s.sink, 0, kSinkFloats * sizeof(float)));
+        CU2REC_HIP(hipHostMalloc(reinterpret_cast<void **>(&s.host_status), sizeof(unsigned), hipHostMallocDefault));
+        *s.host_status = 0;
+        CU2REC_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        for (int i = 0; i < kNumVariants; ++i) {
+            int per_cu = 0;
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kVariants[i].kernel, kResBlock, 0);
+            if (e != hipSuccess) (void)hipGetLastError();
+            s.usable[i] = e == hipSuccess && per_cu >= 1;
+        }
+        s.ready = true;
+    }
+    return s;
+}
+
+}  // namespace
+
+int resident_policy(int set_to) {
+    if (g_policy.load() < 0) {
+        int from_env = kResidentAuto;
+        if (const char *e = std::getenv("CU2REC_RESIDENT")) {
+            const int v = std::atoi(e);
+            if (v >= kResidentOff && v <= kResidentForce) from_env = v;
+        }
+        int expected = -1;
+        g_policy.compare_exchange_strong(expected, from_env);
+    }
+    const int prev = g_policy.load();
+    if (set_to >= kResidentOff && set_to <= kResidentForce) g_policy.store(set_to);
+    return prev;
+}
+
+void resident_check_fault() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    if (dev < static_cast<int>(g_states.size()) && g_states[dev].ready &&
+        *static_cast<volatile unsigned *>(g_states[dev].host_status) != 0)
+        fail(CU2REC_EHIP,
+             "cu2rec_amd: a resident SGD launch gave up at its grid barrier (the grid was not co-resident: is another "
+             "process or stream using this GPU?); the model state is undefined.  CU2REC_RESIDENT=0 selects the "
+             "one-launch-per-iteration kernel");
+}
+
+namespace {
+
+// The launch geometry a call would get, or false if it would stream.  Caller holds g_mutex.
+bool plan_locked(int n_rows, int nslots, int n_iters, int update_items, DeviceState *&state, int &variant, int &blocks,
+                 int &users_per_group) {
+    const int policy = resident_policy(-1);
+    if (policy == kResidentOff || n_iters < 1 || n_rows < 1 || !update_items) return false;
+    const int j = slots_per_lane(nslots);
+    DeviceState &s = state_for_current_device();
+    state = &s;
+    if (s.cus < 1) return false;
+    const long long max_groups = static_cast<long long>(s.cus) * kResGroups;
+    const int need = static_cast<int>(std::min<long long>((n_rows + max_groups - 1) / max_groups, 1 << 20));
+    variant = variant_for(j, need);
+    if (variant < 0 || !s.usable[variant]) return false;  // the rows do not fit the register file: stream them
+    // Auto: the barrier costs a few microseconds where a kernel boundary costs one or two, so residency pays once
+    // an iteration moves enough rows per group and the launch is long enough to amortise loading them.
+    if (policy == kResidentAuto && (need < 4 || n_iters < 4)) return false;
+    users_per_group = kVariants[variant].r;  // >= need: the grid shrinks instead of running empty steps
+    const long long groups = (n_rows + static_cast<long long>(users_per_group) - 1) / users_per_group;
+    blocks = static_cast<int>((groups + kResGroups - 1) / kResGroups);
+    return true;
+}
+
+}  // namespace
+
+bool resident_plan(int n_rows, int n_factors, int n_iters, int *blocks_out, int *users_per_group_out) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState *s = nullptr;
+    int variant = -1, blocks = 0, users_per_group = 0;
+    const bool yes = plan_locked(n_rows, (n_factors + 3) / 4, n_iters, 1, s, variant, blocks, users_per_group);
+    if (blocks_out) *blocks_out = yes ? blocks : 0;
+    if (users_per_group_out) *users_per_group_out = yes ? users_per_group : 0;
+    return yes;
+}
+
+bool resident_launch(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState *sp = nullptr;
+    int variant = -1, blocks = 0, users_per_group = 0;
+    if (!plan_locked(a.n_rows, a.nslots, n_iters, a.update_items, sp, variant, blocks, users_per_group)) return false;
+    DeviceState &s = *sp;
+
+    if (s.have_last && s.last_stream != stream) CU2REC_HIP(hipStreamWaitEvent(stream, s.done, 0));  // never two at once
+    a.iter0 = iter0;
+    a.iters = n_iters;
+    ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink, users_per_group};
+    void *args[] = {&a, &ra};
+    CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));  // counters start from zero; status is sticky
+    CU2REC_HIP(hipLaunchKernel(kVariants[variant].kernel, dim3(blocks), dim3(kResBlock), args, 0, stream));
+    CU2REC_HIP(hipMemcpyAsync(s.host_status, s.words + kBarrierWords, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    CU2REC_HIP(hipEventRecord(s.done, stream));
+    s.last_stream = stream;
+    s.have_last = true;
+    return true;
+}
+
+}  // namespace cu2rec

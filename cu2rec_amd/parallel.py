@@ -51,11 +51,21 @@ class ShardedSGD:
         self.item_weight = None
         # overlap=True: the all-reduce of period t runs while period t+1 trains; its result is folded in at the next
         # sync point (item deltas arrive one period late, local progress made meanwhile is kept).  Default: on for
-        # RCCL, where the collective runs on its own stream next to the SGD kernels; CU2REC_EXCHANGE_OVERLAP=0/1 overrides.
+        # RCCL with the streaming SGD kernel, where the collective runs on its own stream next to the SGD launches;
+        # OFF when Hogwild calls may be resident launches (cu2rec_hogwild_resident != 0, the default): a persistent
+        # grid that needs every CU and an RCCL kernel that needs its peers' kernels running must never wait for
+        # each other's CUs, so there the exchange stays stream-ordered between two launches (it costs a fraction of
+        # a millisecond per epoch; residency saves half of every iteration).  CU2REC_EXCHANGE_OVERLAP=0/1 overrides.
         import os
         if overlap is None:
             env = os.environ.get("CU2REC_EXCHANGE_OVERLAP")
-            overlap = (env == "1") if env in ("0", "1") else (self.world_size > 1 and dist.get_backend(group) == "nccl")
+            if env in ("0", "1"):
+                overlap = env == "1"
+            else:
+                overlap = self.world_size > 1 and dist.get_backend(group) == "nccl"
+                if overlap:
+                    from ._lib import lib
+                    overlap = lib().cu2rec_hogwild_resident(-1) == 0
         self.overlap = bool(overlap) and self.world_size > 1 and hasattr(engine, "apply_item_delta_overlapped")
         self._pending = None
         if self.world_size > 1:

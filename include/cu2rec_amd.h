@@ -171,6 +171,22 @@ int cu2rec_sgd_update(const int *indptr, const int *indices, const float *data, 
  * Returns the previous value; k < 1 only queries. */
 int cu2rec_hogwild_iters_per_launch(int k);
 
+/* Resident Hogwild launches (process-wide; replaces the launch loop of training.cu:107-113 with ONE persistent
+ * launch per cu2rec_sgd_update call).  The iterations of a call keep the reference's cadence -- every user's update
+ * of iteration i is visible to iteration i+1 -- but the boundary between them is a grid-wide barrier instead of a
+ * kernel boundary, and every user's row stays in the register file for the whole call (no P traffic between
+ * iterations).  Applies when all user rows of the CSR fit the register file (e.g. 147,000 users at f <= 128) and
+ * hogwild_iters_per_launch is 1; otherwise the call runs one streaming launch per iteration as before.
+ * policy: 0 never, 1 auto (default: when it fits and a call covers >= 4 iterations), 2 whenever it fits;
+ * CU2REC_RESIDENT=0|1|2 in the environment sets the initial value.  Returns the previous policy; other values query.
+ * A resident launch assumes the GPU to itself (one workgroup per CU, all co-resident).  If it cannot get that, its
+ * barrier gives up after 3 s and the next call into the library returns CU2REC_EHIP. */
+int cu2rec_hogwild_resident(int policy);
+/* 1 if a Hogwild cu2rec_sgd_update call of n_iters iterations on n_rows users would be one resident launch on the
+ * current device under the current policy (then *blocks = workgroups, one per CU, and *users_per_group = rows each
+ * 16-lane group keeps in registers; both may be NULL), 0 if it would stream, < 0 on error. */
+int cu2rec_hogwild_resident_plan(int n_rows, int n_factors, int n_iters, int *blocks, int *users_per_group);
+
 /* Workspace of CU2REC_SGD_ORDERED for one device CSR: item popularity ranks, key/value buffers of the
  * per-iteration schedule, sort scratch.  indptr / indices are device pointers (read once at creation). */
 typedef struct cu2rec_schedule cu2rec_schedule;

@@ -1,0 +1,204 @@
+"""Resident Hogwild launches (-m gpu): one persistent launch per cu2rec_sgd_update call, user rows in the
+register file, a grid-wide barrier where the reference has its kernel boundary (training.cu:107-113).
+
+The barrier is what these tests are about.  Hogwild is racy inside an iteration, so exactness needs inputs
+where the race cannot happen: `_collision_free_set` builds ratings for which, in every iteration of the test,
+no two users sample the same item -- while the SAME item is sampled by different users in different
+iterations.  Then one-launch-per-iteration Hogwild equals the sequential oracle bit for bit, and so must the
+resident launch, but only if every item row written in iteration i is visible in iteration i + 1 to whatever
+CU / XCD reads it next.  A stale read changes bits.
+"""
+import numpy as np
+import pytest
+
+import cu2rec_amd as cu
+from cu2rec_amd import synth
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+HYPER = (0.01, 0.02, 0.02, 0.02, 0.02)
+OFF, AUTO, FORCE = 0, 1, 2
+
+
+class resident_policy:
+    def __init__(self, policy):
+        self.policy = policy
+
+    def __enter__(self):
+        self.prev = cu.lib().cu2rec_hogwild_resident(self.policy)
+
+    def __exit__(self, *exc):
+        cu.lib().cu2rec_hogwild_resident(self.prev)
+
+
+def _as_orc(m):
+    return orc.CSR(m.indptr, m.indices, m.data, m.rows, m.cols, m.global_bias)
+
+
+def _collision_free_set(users, items, degree, iter0, iters, seed, sampler_seed=42, empty_every=0, user_offset=0):
+    """CSR (users x items, `degree` ratings per user, a user in `empty_every` has none) such that for every
+    iteration in [iter0, iter0 + iters) the items sampled by the users are pairwise distinct."""
+    assert items >= 2 * users
+    rng = np.random.RandomState(seed)
+    deg = np.full(users, degree, np.int64)
+    if empty_every:
+        deg[::empty_every] = 0
+    indptr = np.zeros(users + 1, np.int32)
+    np.cumsum(deg, out=indptr[1:])
+    nnz = int(indptr[-1])
+    indices = np.full(nnz, -1, np.int32)
+    used = np.zeros((iters, items), bool)  # used[t, j]: item j is sampled by somebody in iteration iter0 + t
+    shared = 0
+    for u in range(users):
+        lo, hi = int(indptr[u]), int(indptr[u + 1])
+        if lo == hi:
+            continue
+        picks = np.array([orc.sample(sampler_seed, user_offset + u, iter0 + t, lo, hi) for t in range(iters)])
+        mine = set()
+        for k in range(lo, hi):
+            when = np.nonzero(picks == k)[0]
+            while True:
+                j = int(rng.randint(items))
+                if j not in mine and not used[when, j].any():
+                    break
+            shared += int(used[:, j].any())
+            used[when, j] = True
+            mine.add(j)
+            indices[k] = j
+    assert shared > users // 2  # plenty of items are visited by different users in different iterations
+    data = rng.randint(1, 6, nnz).astype(np.float32)
+    return cu.HostCSR(indptr, indices, data, users, items, 3.0)
+
+
+def _run_and_compare(m, f, iter0, iters, policy, update_items=True, chunks=None):
+    P, Q, ub, ib = orc.init_model(m.rows, m.cols, f)
+    model = cu.Model(m.rows, m.cols, f, m.global_bias)
+    d = cu.DeviceCSR(m)
+    with resident_policy(policy):
+        it = iter0
+        for n in (chunks or [iters]):
+            model.sgd(d, HYPER, 42, it, n, mode="hogwild", update_items=update_items)
+            it += n
+        assert it == iter0 + iters
+    orc.sgd_iterations(_as_orc(m), P, Q, ub, ib, m.global_bias, HYPER, 42, iter0, iters, dot_order=orc.DOT_TREE16,
+                       update_items=update_items)
+    for name, g, w in zip(("P", "Q", "user_bias", "item_bias"), model.download(), (P, Q, ub, ib)):
+        np.testing.assert_array_equal(g, w, err_msg=name)
+
+
+@pytest.fixture(scope="module")
+def ml20m_like():
+    # 60,000 users on the 8,192 groups of a 256-CU grid: 8 resident users per group (f = 100: two float4 per lane)
+    return _collision_free_set(60000, 120000, 6, 0, 12, seed=1, empty_every=97)
+
+
+def test_collision_free_set_is_exact_with_one_launch_per_iteration(ml20m_like):
+    """Control: on this input the streaming kernel (one launch per iteration) IS the sequential result."""
+    _run_and_compare(ml20m_like, 100, 0, 12, OFF)
+
+
+def test_resident_launch_bit_exact_across_the_grid_barrier(ml20m_like):
+    """Twelve iterations in ONE launch: equal to the oracle bit for bit, i.e. no stale item row anywhere."""
+    _run_and_compare(ml20m_like, 100, 0, 12, FORCE)
+
+
+def test_resident_auto_policy_and_chunked_calls(ml20m_like):
+    """Default policy takes the resident path here (8 users per group, calls of >= 4 iterations); calls of 5 + 4 + 3
+    iterations (the last one streams) continue each other exactly."""
+    assert cu.lib().cu2rec_hogwild_resident(-1) == AUTO
+    _run_and_compare(ml20m_like, 100, 0, 12, AUTO, chunks=[5, 4, 3])
+
+
+@pytest.mark.parametrize("f,users", [(50, 40000), (64, 9000), (128, 147000), (160, 30000), (256, 20000), (8, 700)])
+def test_resident_every_row_width(f, users):
+    """J = 1..4 float4 slots per lane, few and many users per group (147,000 users at f = 128 is the 18 per group the
+    registers hold), a grid smaller than the chip (700 users), resume from a non-zero iteration."""
+    m = _collision_free_set(users, 2 * users + 64, 4, 7, 6, seed=f, empty_every=0 if users < 1000 else 41)
+    _run_and_compare(m, f, 7, 6, FORCE)
+
+
+def test_resident_frozen_items_need_no_barrier():
+    """is_train == false: item side untouched, users fit as in predict.cu; equal to the oracle on ANY input
+    because nothing is shared between users."""
+    tr, _ = synth.make_ratings(30000, 500, 400000, min_degree=3, seed=5)
+    _run_and_compare(tr, 100, 3, 9, FORCE, update_items=False)
+
+
+def test_resident_falls_back_when_the_rows_do_not_fit():
+    """More users than the register file holds (f = 256: 9 per group): the call streams instead, same results."""
+    m = _collision_free_set(80000, 160064, 3, 0, 4, seed=9)
+    _run_and_compare(m, 256, 0, 4, FORCE)
+
+
+def test_resident_one_iteration_is_jacobi():
+    """The Hogwild contract inside an iteration (as for the streaming kernel): users / items touched by exactly one
+    update equal the oracle's single update bit for bit; untouched items keep their bits."""
+    tr, _ = synth.make_ratings(40000, 3000, 600000, min_degree=3, seed=9)
+    f = 100
+    rng = np.random.RandomState(2)
+    P0, Q0 = (rng.randn(tr.rows, f) * 0.1).astype(np.float32), (rng.randn(tr.cols, f) * 0.1).astype(np.float32)
+    ub0, ib0 = (rng.randn(tr.rows) * 0.1).astype(np.float32), (rng.randn(tr.cols) * 0.1).astype(np.float32)
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias, P0, Q0, ub0, ib0)
+    with resident_policy(FORCE):
+        model.sgd(cu.DeviceCSR(tr), HYPER, 42, 5, 1, mode="hogwild")
+    gP, gQ, gub, gib = model.download()
+    items = np.array([tr.indices[orc.sample(42, u, 5, tr.indptr[u], tr.indptr[u + 1])] for u in range(tr.rows)])
+    counts = np.bincount(items, minlength=tr.cols)
+    o = _as_orc(tr)
+    singles = np.nonzero(counts[items] == 1)[0]
+    assert len(singles) > 20
+    for u in singles[:400]:
+        P, Q, ub, ib = P0.copy(), Q0.copy(), ub0.copy(), ib0.copy()
+        orc.sgd_one(o, int(u), P, Q, ub, ib, tr.global_bias, HYPER, 42, 5, dot_order=orc.DOT_TREE16)
+        np.testing.assert_array_equal(gP[u], P[u])
+        np.testing.assert_array_equal(gQ[items[u]], Q[items[u]])
+        assert gub[u] == ub[u] and gib[items[u]] == ib[items[u]]
+    np.testing.assert_array_equal(gQ[counts == 0], Q0[counts == 0])
+    assert np.isfinite(gP).all() and np.isfinite(gQ).all()
+
+
+def test_resident_converges_like_streaming_and_the_oracle():
+    """Real (colliding) ratings: resident and streaming Hogwild are the same algorithm, so 300 iterations end at the
+    same test RMSE up to the outcome of the race -- which users of an iteration overlap in time differs (a resident
+    grid has ALL of them in flight at once, a streamed iteration runs in waves of workgroups), so popular items lose
+    a few more or a few fewer updates: 5e-3 here, 1e-4 on the ML-20M shape.  Both within 2e-2 of the
+    sequential oracle."""
+    tr, te = synth.make_ratings(40000, 6000, 1200000, min_degree=5, seed=11)
+    f, iters = 32, 300
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    start = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias)["rmse"]
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, iters, dot_order=orc.DOT_TREE16)
+    want = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias)["rmse"]
+    d_tr, d_te = cu.DeviceCSR(tr), cu.DeviceCSR(te)
+    got = {}
+    for policy in (OFF, FORCE):
+        model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+        with resident_policy(policy):
+            model.sgd(d_tr, HYPER, 42, 0, iters, mode="hogwild")
+        got[policy] = model.loss(d_te)["rmse"]
+    assert want < start - 0.03
+    assert abs(got[FORCE] - got[OFF]) < 5e-3
+    assert abs(got[FORCE] - want) < 2e-2 and abs(got[OFF] - want) < 2e-2
+
+
+def test_resident_through_the_raw_pointer_abi_with_user_offset():
+    """cu2rec_sgd_update on torch-owned buffers (the multi-GPU plumbing): a shard whose users are global ids
+    [u0, u0 + n) draws what the unsharded run draws for them."""
+    from cu2rec_amd.engine import DeviceRatings, Engine
+    u0, n, f = 5000, 50000, 100
+    m = _collision_free_set(n, 2 * n + 64, 4, 2, 8, seed=3, user_offset=u0)
+    P, Q, ub, ib = orc.init_model(n, m.cols, f)
+    eng = Engine(n, m.cols, f, m.global_bias, P.copy(), Q.copy(), ub.copy(), ib.copy())
+    with resident_policy(FORCE):
+        eng.sgd(DeviceRatings(m, eng.device), HYPER, 42, 2, 8, cu.SGD_HOGWILD, True, u0)
+    # oracle: the same users placed at their global ids behind u0 empty users
+    big = cu.HostCSR(np.concatenate([np.zeros(u0, np.int32), m.indptr]), m.indices, m.data, u0 + n, m.cols, m.global_bias)
+    Pb, ubb = np.zeros((u0 + n, f), np.float32), np.zeros(u0 + n, np.float32)
+    Pb[u0:], ubb[u0:] = P, ub
+    orc.sgd_iterations(_as_orc(big), Pb, Q, ubb, ib, m.global_bias, HYPER, 42, 2, 8, dot_order=orc.DOT_TREE16)
+    gP, gQ, gub, gib = eng.download()
+    np.testing.assert_array_equal(gP, Pb[u0:])
+    np.testing.assert_array_equal(gQ, Q)
+    np.testing.assert_array_equal(gub, ubb[u0:])
+    np.testing.assert_array_equal(gib, ib)
