@@ -307,12 +307,18 @@ def train(train_matrix, test_matrix, cfg, Q=None, item_bias=None, global_bias=No
 # ------------------------------------------------------------------------------------------ raw device pointers
 
 def sgd_update(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,
-               hyper, seed, iter0, n_iters, mode=SGD_HOGWILD, update_items=True, user_offset=0, stream=None):
-    """cu2rec_sgd_update on raw device addresses (ints)."""
+               hyper, seed, iter0, n_iters, mode=SGD_HOGWILD, update_items=True, user_offset=0, stream=None,
+               sample_pairs=None):
+    """cu2rec_sgd_update(_ex) on raw device addresses (ints); sample_pairs: the optional side-by-side sample array."""
     h = hyper if isinstance(hyper, Hyper) else Hyper(*[float(x) for x in hyper])
-    check(lib().cu2rec_sgd_update(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias,
-                                  float(global_bias), n_factors, C.byref(h), int(seed), int(iter0), int(n_iters),
-                                  _mode(mode), 1 if update_items else 0, int(user_offset), stream))
+    check(lib().cu2rec_sgd_update_ex(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias,
+                                     float(global_bias), n_factors, C.byref(h), int(seed), int(iter0), int(n_iters),
+                                     _mode(mode), 1 if update_items else 0, int(user_offset), sample_pairs, stream))
+
+
+def sample_pairs_build(indices, data, nnz, pairs, stream=None):
+    """cu2rec_sample_pairs_build on raw device addresses: pairs[k] = {indices[k], data[k]}."""
+    check(lib().cu2rec_sample_pairs_build(indices, data, int(nnz), pairs, stream))
 
 
 class Schedule:

@@ -85,7 +85,7 @@ SgdArgs make_sgd_args(const int *indptr, const int *indices, const float *data, 
 void sgd_update(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P, int ldp,
                 float *Q, int ldq, float *user_bias, float *item_bias, float global_bias, int n_factors,
                 const cu2rec_hyper &hyper, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
-                int user_offset, hipStream_t stream) {
+                int user_offset, hipStream_t stream, const void *sample_pairs) {
     require(mode == CU2REC_SGD_HOGWILD || mode == CU2REC_SGD_SERIAL,
             "cu2rec_sgd_update: unknown mode (CU2REC_SGD_ORDERED needs cu2rec_sgd_update_ordered and a schedule)");
     require(n_iters >= 0, "cu2rec_sgd_update: bad iteration count");
@@ -94,6 +94,8 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
     if (n_rows == 0 || n_iters == 0) return;
     require_device();
     resident_check_fault();
+    require((reinterpret_cast<uintptr_t>(sample_pairs) & 7u) == 0, "cu2rec_sgd_update: sample pairs must be 8-byte aligned");
+    a.pairs = static_cast<const uint2 *>(sample_pairs);
     if (mode == CU2REC_SGD_SERIAL) {
         // one launch walks all iterations in order
         a.iter0 = iter0;
@@ -112,6 +114,16 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
             launch_sgd(a, mode, stream);
         }
     }
+    CU2REC_HIP(hipGetLastError());
+}
+
+void sample_pairs_build(const int *indices, const float *data, int nnz, void *pairs, hipStream_t stream) {
+    require(nnz >= 0, "cu2rec_sample_pairs_build: bad size");
+    if (nnz == 0) return;
+    require(indices && data && pairs, "cu2rec_sample_pairs_build: null device pointer");
+    require((reinterpret_cast<uintptr_t>(pairs) & 7u) == 0, "cu2rec_sample_pairs_build: pairs must be 8-byte aligned");
+    require_device();
+    launch_sample_pairs_build(indices, data, static_cast<size_t>(nnz), static_cast<uint2 *>(pairs), stream);
     CU2REC_HIP(hipGetLastError());
 }
 
@@ -283,8 +295,18 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
                            update_items, 0, stream);
         return;
     }
+    const void *pairs = nullptr;
+    if (mode == CU2REC_SGD_HOGWILD && update_items && train.nnz > 0 &&
+        resident_plan(train.rows, n_factors, n_iters, nullptr, nullptr)) {
+        if (!train.pairs.ptr) {  // first resident call on this CSR: 8 bytes per rating, built once
+            train.pairs.allocate(train.nnz);
+            sample_pairs_build(train.indices.ptr, train.data.ptr, train.nnz, train.pairs.ptr, stream);
+        }
+        pairs = train.pairs.ptr;
+    }
     sgd_update(train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr, ld, Q.ptr, ld,
-               user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters, mode, update_items, 0, stream);
+               user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters, mode, update_items, 0, stream,
+               pairs);
 }
 
 void DeviceModel::loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq, float *mae, float *rmse,
@@ -350,6 +372,23 @@ int cu2rec_sgd_update(const int *indptr, const int *indices, const float *data, 
         sgd_update(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,
                    *hyper, seed, iter0, n_iters, mode, update_items, user_offset, as_stream(stream));
     });
+}
+
+int cu2rec_sgd_update_ex(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P,
+                         int ldp, float *Q, int ldq, float *user_bias, float *item_bias, float global_bias, int n_factors,
+                         const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
+                         int user_offset, const void *sample_pairs, void *stream) {
+    return guarded([&] {
+        require(hyper, "cu2rec_sgd_update_ex: hyper is null");
+        sgd_update(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,
+                   *hyper, seed, iter0, n_iters, mode, update_items, user_offset, as_stream(stream), sample_pairs);
+    });
+}
+
+size_t cu2rec_sample_pairs_bytes(int nnz) { return nnz > 0 ? static_cast<size_t>(nnz) * 8 : 0; }
+
+int cu2rec_sample_pairs_build(const int *indices, const float *data, int nnz, void *pairs, void *stream) {
+    return guarded([&] { sample_pairs_build(indices, data, nnz, pairs, as_stream(stream)); });
 }
 
 int cu2rec_hogwild_iters_per_launch(int k) {

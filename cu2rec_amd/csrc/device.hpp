@@ -23,7 +23,10 @@ SgdArgs make_sgd_args(const int *indptr, const int *indices, const float *data, 
 void sgd_update(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P, int ldp,
                 float *Q, int ldq, float *user_bias, float *item_bias, float global_bias, int n_factors,
                 const cu2rec_hyper &hyper, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
-                int user_offset, hipStream_t stream);
+                int user_offset, hipStream_t stream, const void *sample_pairs = nullptr);
+
+// [nnz] x {item, rating} side by side for SgdArgs::pairs (8 bytes per rating, device memory)
+void sample_pairs_build(const int *indices, const float *data, int nnz, void *pairs, hipStream_t stream);
 
 void sgd_update_ordered(OrderedSchedule &schedule, const int *indptr, const int *indices, const float *data,
                         int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
@@ -46,6 +49,7 @@ struct DeviceCsr {
     int max_item;
     int users_with_ratings;
     mutable std::unique_ptr<OrderedSchedule> schedule;  // created on first CU2REC_SGD_ORDERED use
+    mutable DeviceBuffer<uint2> pairs;                   // sample array, created on first Hogwild use (SgdArgs::pairs)
 };
 
 // P, Q, biases on the device with padded rows (see include/cu2rec_amd.h "Device data layout").

@@ -208,6 +208,15 @@ __global__ __launch_bounds__(kBlock) void error_metrics_kernel(const float *__re
     }
 }
 
+// ---- sample array: indices[k] and data[k] side by side (SgdArgs::pairs) ----------------------------------------
+__global__ __launch_bounds__(kBlock) void sample_pairs_build_kernel(const int *__restrict__ indices,
+                                                                    const float *__restrict__ data, size_t nnz,
+                                                                    uint2 *__restrict__ pairs) {
+    for (size_t k = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; k < nnz;
+         k += static_cast<size_t>(gridDim.x) * kBlock)
+        pairs[k] = make_uint2(static_cast<unsigned>(indices[k]), __float_as_uint(data[k]));
+}
+
 // ---- multi-GPU item-factor exchange helpers -------------------------------------------------
 __global__ __launch_bounds__(kBlock) void items_delta_pack_kernel(const float *__restrict__ Q,
                                                                   const float *__restrict__ ib,
@@ -337,6 +346,11 @@ int error_metrics_blocks(int n) { return blocks_for(static_cast<size_t>(n), kBlo
 
 void launch_error_metrics(const float *errors, int n, double *partials, int blocks, hipStream_t stream) {
     hipLaunchKernelGGL(error_metrics_kernel, dim3(blocks), dim3(kBlock), 0, stream, errors, n, partials);
+}
+
+void launch_sample_pairs_build(const int *indices, const float *data, size_t nnz, uint2 *pairs, hipStream_t stream) {
+    const int blocks = blocks_for(nnz, kBlock * 8, 8192);
+    hipLaunchKernelGGL(sample_pairs_build_kernel, dim3(blocks), dim3(kBlock), 0, stream, indices, data, nnz, pairs);
 }
 
 void launch_items_delta_pack(const float *Q, const float *ib, const float *Q_base, const float *ib_base, int n_cols,

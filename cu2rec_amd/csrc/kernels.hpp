@@ -34,6 +34,10 @@ struct SgdArgs {
     int iters;            // updates per user in this launch
     int update_items;     // 0: Q and item_bias frozen (is_train == false)
     int user_offset;      // global id of row 0 (user-sharded runs); enters the sampler only
+    // optional sample array: [nnz] x {int32 item, float32 rating}, i.e. indices[k] and data[k] side by side, so that a
+    // draw is ONE 8-byte gather instead of two 4-byte gathers in different arrays (used by the resident launches,
+    // where the draws are a third of the random accesses); nullptr: gather from indices / data
+    const uint2 *pairs;
 };
 
 struct LossArgs {
@@ -59,6 +63,7 @@ int loss_blocks(int nnz);
 void launch_loss(const LossArgs &args, int blocks, hipStream_t stream);
 int error_metrics_blocks(int n);
 void launch_error_metrics(const float *errors, int n, double *partials, int blocks, hipStream_t stream);
+void launch_sample_pairs_build(const int *indices, const float *data, size_t nnz, uint2 *pairs, hipStream_t stream);
 void launch_items_delta_pack(const float *Q, const float *ib, const float *Q_base, const float *ib_base, int n_cols,
                              int ldq, float *buf, hipStream_t stream);
 void launch_items_delta_apply_overlapped(float *Q, float *ib, float *Q_base, float *ib_base, const float *Q_snap,

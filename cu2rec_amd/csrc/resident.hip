@@ -266,8 +266,14 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
             if (my_n[m] > 0) {
                 const int y_i = sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + my_x[m]), it, my_low[m],
                                               my_low[m] + my_n[m]);
-                item[m] = a.indices[y_i];
-                rating[m] = a.data[y_i];
+                if (a.pairs != nullptr) {  // one 8-byte gather (SgdArgs::pairs)
+                    const uint2 ir = a.pairs[y_i];
+                    item[m] = static_cast<int>(ir.x);
+                    rating[m] = __uint_as_float(ir.y);
+                } else {
+                    item[m] = a.indices[y_i];
+                    rating[m] = a.data[y_i];
+                }
             }
         }
     };

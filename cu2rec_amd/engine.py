@@ -29,6 +29,15 @@ class DeviceRatings:
         self.data = torch.from_numpy(host.data if host.nnz else np.zeros(1, np.float32)).to(device)
         self.global_bias = host.global_bias
         self._schedule = None
+        self._pairs = None
+
+    def sample_pairs(self):
+        """The side-by-side {item, rating} sample array of this CSR (8 bytes per rating), built on first use."""
+        if self._pairs is None and self.nnz:
+            self._pairs = torch.empty(self.nnz, dtype=torch.int64, device=self.indices.device)
+            api.sample_pairs_build(self.indices.data_ptr(), self.data.data_ptr(), self.nnz, self._pairs.data_ptr(),
+                                   _stream_ptr())
+        return self._pairs
 
     def schedule(self):
         """Ordered-mode workspace for this CSR, created on first use."""
@@ -80,10 +89,14 @@ class Engine:
                                    self.global_bias, self.f, hyper, seed, iter0, n_iters, update_items, user_offset,
                                    _stream_ptr())
             return
+        pairs = None
+        if (api._mode(mode) == api.SGD_HOGWILD and update_items and ratings.nnz and hasattr(ratings, "sample_pairs")
+                and lib().cu2rec_hogwild_resident_plan(ratings.rows, self.f, n_iters, None, None) == 1):
+            pairs = ratings.sample_pairs().data_ptr()  # resident launch: one 8-byte gather per draw
         api.sgd_update(ratings.indptr.data_ptr(), ratings.indices.data_ptr(), ratings.data.data_ptr(), ratings.rows,
                        self.cols, self.P.data_ptr(), self.ld, self.Q.data_ptr(), self.ld, self.user_bias.data_ptr(),
                        self.item_bias.data_ptr(), self.global_bias, self.f, hyper, seed, iter0, n_iters, mode,
-                       update_items, user_offset, _stream_ptr())
+                       update_items, user_offset, _stream_ptr(), pairs)
 
     def loss(self, ratings, want_errors=False):
         assert ratings.rows <= self.rows and ratings.cols <= self.cols

@@ -164,6 +164,20 @@ int cu2rec_sgd_update(const int *indptr, const int *indices, const float *data, 
                       int n_factors, const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters,
                       int mode, int update_items, int user_offset, void *stream);
 
+/* Optional sample array for the Hogwild path: [nnz] x {int32 item, float32 rating} = indices[k] and data[k] of the
+ * CSR side by side (8 bytes per rating, device memory, 8-byte aligned), so that drawing a rating (sgd.cu:36-44) is
+ * one 8-byte gather instead of two 4-byte gathers in different arrays.  The reference's CSR stays the input
+ * format; this is a derived copy the caller owns: allocate cu2rec_sample_pairs_bytes(nnz), fill it once with
+ * cu2rec_sample_pairs_build, pass it to cu2rec_sgd_update_ex (NULL = gather from indices / data; results are
+ * identical either way).  Used by the resident launches (below); the owned-object layer (cu2rec_model_sgd,
+ * cu2rec_train) keeps one per cu2rec_csr by itself. */
+size_t cu2rec_sample_pairs_bytes(int nnz);
+int cu2rec_sample_pairs_build(const int *indices, const float *data, int nnz, void *pairs, void *stream);
+int cu2rec_sgd_update_ex(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols,
+                         float *P, int ldp, float *Q, int ldq, float *user_bias, float *item_bias, float global_bias,
+                         int n_factors, const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters,
+                         int mode, int update_items, int user_offset, const void *sample_pairs, void *stream);
+
 /* Hogwild launch blocking (process-wide, default 1 = the reference's cadence: one launch per iteration, every user's
  * update of iteration i visible before iteration i+1 starts, training.cu:107-113).  With k > 1 a launch performs k
  * consecutive updates per user with the user's row held in registers (P traffic / k); users are then up to k-1

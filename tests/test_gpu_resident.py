@@ -182,16 +182,29 @@ def test_resident_converges_like_streaming_and_the_oracle():
     assert abs(got[FORCE] - want) < 2e-2 and abs(got[OFF] - want) < 2e-2
 
 
-def test_resident_through_the_raw_pointer_abi_with_user_offset():
-    """cu2rec_sgd_update on torch-owned buffers (the multi-GPU plumbing): a shard whose users are global ids
-    [u0, u0 + n) draws what the unsharded run draws for them."""
+@pytest.mark.parametrize("with_pairs", [True, False])
+def test_resident_through_the_raw_pointer_abi_with_user_offset(with_pairs):
+    """cu2rec_sgd_update_ex on torch-owned buffers (the multi-GPU plumbing): a shard whose users are global ids
+    [u0, u0 + n) draws what the unsharded run draws for them -- with the side-by-side sample array
+    (cu2rec_sample_pairs_build, one 8-byte gather per draw) and without it (two 4-byte gathers): same bits."""
+    from cu2rec_amd import api
     from cu2rec_amd.engine import DeviceRatings, Engine
     u0, n, f = 5000, 50000, 100
     m = _collision_free_set(n, 2 * n + 64, 4, 2, 8, seed=3, user_offset=u0)
     P, Q, ub, ib = orc.init_model(n, m.cols, f)
     eng = Engine(n, m.cols, f, m.global_bias, P.copy(), Q.copy(), ub.copy(), ib.copy())
+    d = DeviceRatings(m, eng.device)
     with resident_policy(FORCE):
-        eng.sgd(DeviceRatings(m, eng.device), HYPER, 42, 2, 8, cu.SGD_HOGWILD, True, u0)
+        if with_pairs:
+            eng.sgd(d, HYPER, 42, 2, 8, cu.SGD_HOGWILD, True, u0)
+            assert d._pairs is not None
+            packed = d._pairs.cpu().numpy()
+            np.testing.assert_array_equal((packed & 0xFFFFFFFF).astype(np.int32), m.indices)
+            np.testing.assert_array_equal((packed >> 32).astype(np.uint32).view(np.float32), m.data)
+        else:
+            api.sgd_update(d.indptr.data_ptr(), d.indices.data_ptr(), d.data.data_ptr(), n, m.cols, eng.P.data_ptr(), eng.ld,
+                           eng.Q.data_ptr(), eng.ld, eng.user_bias.data_ptr(), eng.item_bias.data_ptr(), eng.global_bias, f,
+                           HYPER, 42, 2, 8, cu.SGD_HOGWILD, True, u0, None, None)
     # oracle: the same users placed at their global ids behind u0 empty users
     big = cu.HostCSR(np.concatenate([np.zeros(u0, np.int32), m.indptr]), m.indices, m.data, u0 + n, m.cols, m.global_bias)
     Pb, ubb = np.zeros((u0 + n, f), np.float32), np.zeros(u0 + n, np.float32)
