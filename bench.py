@@ -5,8 +5,10 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one reference iteration: one SGD update for every user with at least one rating
-(sgd.cu:27-37), i.e. one launch of the SGD kernel over the rank's users.  Inputs (CSR, P, Q,
-biases) are resident in HBM before the timed region.  For N > 1 every rank holds its own
+(sgd.cu:27-37).  The library is called with 100 iterations at a time (N > 1: one exchange period);
+such a call is ONE resident launch (user rows in the register file, a grid barrier between
+iterations: cu2rec_amd/csrc/resident.hip) when the rows fit, else one launch per iteration.
+Inputs (CSR, P, Q, biases) are resident in HBM before the timed region.  For N > 1 every rank holds its own
 ML-20M-sized user population (weak scaling; same item set) and the replicas of Q / item_bias are
 reconciled by one RCCL all-reduce every `--sync-every` steps (default: one epoch = nnz / users
 steps), inside the timed region.
@@ -211,7 +213,12 @@ def main():
     log("dataset ready: %d users, %d items, %d train ratings" % (train.rows, train.cols, train.nnz))
     f = args.factors
     hyper = (0.01, 0.02, 0.02, 0.02, 0.02)  # preprocessing/create_config.py:25-32
-    sync_every = args.sync_every or max(1, int(round(train.nnz / max(int(np.count_nonzero(np.diff(train.indptr))), 1))))
+    # iterations per cu2rec_sgd_update call: N > 1 -> the exchange period (default one epoch = nnz / users iterations);
+    # N = 1 -> nothing to exchange, 100 per call so that every launch of the run has the same length
+    if world > 1:
+        sync_every = args.sync_every or max(1, int(round(train.nnz / max(int(np.count_nonzero(np.diff(train.indptr))), 1))))
+    else:
+        sync_every = args.sync_every or 100
     user_offset = rank * train.rows  # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the population
     if args.scaling == "strong" and world > 1:
         from cu2rec_amd.parallel import plan_users
@@ -246,6 +253,8 @@ def main():
     elapsed = time.perf_counter() - t0
     it += args.steps
     log("timed region: %d steps in %.4f s" % (args.steps, elapsed))
+    final = job.loss(d_test)  # the model after warmup + steps iterations, before the untimed extra passes below
+    final_iterations = it
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -297,9 +306,6 @@ def main():
                      "algorithmic_bytes_per_launch": s_bytes, "achieved_GBs": s_bytes / (s_ms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         log("streaming kernel: avg %.2f us per launch, %.4f ms/step" % (1e3 * s_ms, streaming["ms_per_step"]))
-    final = job.loss(d_test)
-    final_iterations = it
-
     # ---- the fused loss pass (train set), timed the same way: the other kernel of the path
     le = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
     for a, b in le:

@@ -52,6 +52,9 @@
                              // stores, 8 no item-row loads; never set in the shipped library
 #endif
 
+#ifndef CU2REC_RES_NT_PAIRS
+#define CU2REC_RES_NT_PAIRS 0  // 1: non-temporal hint on the sample gathers (each line is used once)
+#endif
 #ifndef CU2REC_RES_D2
 #define CU2REC_RES_D2 3  // item rows in flight per group at two float4 per lane (f = 68..128)
 #endif
@@ -267,7 +270,12 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
                 const int y_i = sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + my_x[m]), it, my_low[m],
                                               my_low[m] + my_n[m]);
                 if (a.pairs != nullptr) {  // one 8-byte gather (SgdArgs::pairs)
+#if CU2REC_RES_NT_PAIRS
+                    typedef unsigned uvec2 __attribute__((ext_vector_type(2)));
+                    const uvec2 ir = __builtin_nontemporal_load(reinterpret_cast<const uvec2 *>(a.pairs) + y_i);
+#else
                     const uint2 ir = a.pairs[y_i];
+#endif
                     item[m] = static_cast<int>(ir.x);
                     rating[m] = __uint_as_float(ir.y);
                 } else {
