@@ -512,6 +512,9 @@ bool plan_locked(int n_rows, int nslots, int n_iters, int update_items, DeviceSt
     users_per_group = kVariants[variant].r;  // >= need: the grid shrinks instead of running empty steps
     const long long groups = (n_rows + static_cast<long long>(users_per_group) - 1) / users_per_group;
     blocks = static_cast<int>((groups + kResGroups - 1) / kResGroups);
+#ifdef CU2REC_RES_TEST_OVERSUBSCRIBE  // fault-path check only (tools/build_variant.sh): a grid that cannot be co-resident
+    blocks *= CU2REC_RES_TEST_OVERSUBSCRIBE;
+#endif
     return true;
 }
 
