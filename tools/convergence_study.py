@@ -4,7 +4,9 @@ sequential (mf_sequential.cu) trajectory -- the parity tests show it bit-identic
 as the reference curve here; this tool itself never touches oracle/.
 
 usage: tools/convergence_study.py [--workload ml-1m] [--factors 50] [--iters 2000] [--every 250]
-                                  [--modes hogwild,hogwild:4,ordered]     (mode:k = k iterations per Hogwild launch)
+                                  [--modes hogwild,hogwild-streaming,hogwild:4,ordered]
+       hogwild = the default policy (resident launches when the rows fit), hogwild-streaming = one launch per iteration,
+       mode:k = k iterations per Hogwild launch without a barrier (opt-in blocking)
 """
 import argparse
 import json
@@ -38,6 +40,11 @@ def main():
         if ":" in mode:  # e.g. hogwild:4 = Hogwild with 4 iterations per launch
             mode, block = mode.split(":")[0], int(mode.split(":")[1])
         cu.lib().cu2rec_hogwild_iters_per_launch(block)
+        label = mode
+        prev_policy = cu.lib().cu2rec_hogwild_resident(-1)
+        if mode == "hogwild-streaming":  # one launch per iteration, user rows through HBM (CU2REC_RESIDENT=0)
+            mode = "hogwild"
+            cu.lib().cu2rec_hogwild_resident(0)
         model = cu.Model(train.rows, train.cols, f, train.global_bias)
         curve, t_sgd = [(0, model.loss(d_te)["rmse"], model.loss(d_tr)["rmse"])], 0.0
         for it in range(0, args.iters, args.every):
@@ -47,7 +54,8 @@ def main():
             t_sgd += time.perf_counter() - t0
             curve.append((it + args.every, r["rmse"], model.loss(d_tr)["rmse"]))
         cu.lib().cu2rec_hogwild_iters_per_launch(1)
-        mode = mode if block == 1 else "%s_x%d" % (mode, block)
+        cu.lib().cu2rec_hogwild_resident(prev_policy)
+        mode = label if block == 1 else "%s_x%d" % (label, block)
         out["curves"][mode] = {"points": curve, "seconds": t_sgd}
         print(mode, "%.2fs" % t_sgd, " ".join("%d:%.5f" % (a, b) for a, b, _ in curve), flush=True)
     print(json.dumps(out))
