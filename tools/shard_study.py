@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--shards", default="2,8")
     ap.add_argument("--sync", default="16,115")
     ap.add_argument("--mode", default="hogwild")
+    ap.add_argument("--merges", default="mean,sum,weighted")
+    ap.add_argument("--sequential", action="store_true",
+                    help="also run the unsharded set in ordered mode (= mf_sequential.cu's result, bit for bit) as the reference")
     args = ap.parse_args()
     import torch
 
@@ -53,6 +56,13 @@ def main():
     results.append({"shards": 1, "rmse": ref})
     print("N=1 rmse %.5f" % ref, flush=True)
     del base
+    if args.sequential:
+        seq = Engine(train.rows, train.cols, f, train.global_bias, device=dev)
+        seq.sgd(DeviceRatings(train, dev), hyper, 42, 0, args.iters, "ordered")
+        r = test_rmse([seq], [(0, train.rows)])
+        results.append({"shards": 1, "mode": "ordered (sequential semantics)", "rmse": r})
+        print("N=1 sequential (ordered mode) rmse %.5f (%+.5f vs N=1 %s)" % (r, r - ref, args.mode), flush=True)
+        del seq
     for n in [int(v) for v in args.shards.split(",")]:
         b = plan_users(train.rows, n)
         bounds = list(zip(b[:-1], b[1:]))
@@ -61,7 +71,7 @@ def main():
         tot = rates.sum(0)
         weights = torch.tensor(np.where(tot > 0, rates / np.maximum(tot, 1e-300), 1.0 / n), dtype=torch.float32, device=dev)
         for sync in [int(v) for v in args.sync.split(",")]:
-            for merge in ("mean", "sum", "weighted"):
+            for merge in args.merges.split(","):
                 engines = [Engine(u1 - u0, train.cols, f, train.global_bias, P=P0[u0:u1], user_bias=ub0[u0:u1], device=dev)
                            for u0, u1 in bounds]
                 d = [DeviceRatings(s, dev) for s in shards]
