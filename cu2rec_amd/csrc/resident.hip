@@ -484,11 +484,17 @@ void resident_check_fault() {
         return;
     }
     if (dev < static_cast<int>(g_states.size()) && g_states[dev].ready &&
-        *static_cast<volatile unsigned *>(g_states[dev].host_status) != 0)
+        *static_cast<volatile unsigned *>(g_states[dev].host_status) != 0) {
+        // reported once: the words are cleared so that the process can go on (e.g. with cu2rec_hogwild_resident(0))
+        DeviceState &s = g_states[dev];
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(s.words + kBarrierWords, 0, sizeof(unsigned));
+        *s.host_status = 0;
         fail(CU2REC_EHIP,
              "cu2rec_amd: a resident SGD launch gave up at its grid barrier (the grid was not co-resident: is another "
              "process or stream using this GPU?); the model state is undefined.  CU2REC_RESIDENT=0 selects the "
              "one-launch-per-iteration kernel");
+    }
 }
 
 namespace {

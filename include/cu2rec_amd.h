@@ -194,7 +194,8 @@ int cu2rec_hogwild_iters_per_launch(int k);
  * policy: 0 never, 1 auto (default: when it fits and a call covers >= 4 iterations), 2 whenever it fits;
  * CU2REC_RESIDENT=0|1|2 in the environment sets the initial value.  Returns the previous policy; other values query.
  * A resident launch assumes the GPU to itself (one workgroup per CU, all co-resident).  If it cannot get that, its
- * barrier gives up after 3 s and the next call into the library returns CU2REC_EHIP. */
+ * barrier gives up after 3 s and the next call into the library returns CU2REC_EHIP (once: the model state is
+ * undefined after that, but the library stays usable, e.g. with policy 0). */
 int cu2rec_hogwild_resident(int policy);
 /* 1 if a Hogwild cu2rec_sgd_update call of n_iters iterations on n_rows users would be one resident launch on the
  * current device under the current policy (then *blocks = workgroups, one per CU, and *users_per_group = rows each
