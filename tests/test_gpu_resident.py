@@ -215,3 +215,29 @@ def test_resident_through_the_raw_pointer_abi_with_user_offset(with_pairs):
     np.testing.assert_array_equal(gQ, Q)
     np.testing.assert_array_equal(gub, ubb[u0:])
     np.testing.assert_array_equal(gib, ib)
+
+
+def test_train_loop_with_resident_segments_equals_the_oracle(ml20m_like):
+    """cu2rec_train (training.cu:21-204) in Hogwild mode: the stretches between two loss checks (1, 3, 4, 4
+    iterations for check_error = 4) run as streaming launches and as resident launches (default policy: >= 4
+    iterations per call); on the collision-free input the whole run -- factors, the loss at every check, the learning
+    rate after patience decay -- equals the oracle's train() bit for bit."""
+    m = ml20m_like  # collision free for iterations 0..11
+    rng = np.random.RandomState(7)
+    te = cu.HostCSR(np.arange(0, 3 * 2000 + 1, 3, dtype=np.int32), rng.randint(0, m.cols, 6000).astype(np.int32),
+                    rng.randint(1, 6, 6000).astype(np.float32), 2000, m.cols, m.global_bias)
+    kw = dict(total_iterations=12, n_factors=100, check_error=4, learning_rate=0.05, patience=1.0, seed=42)
+    cfg, ocfg = cu.default_config(**kw), orc.default_config(**kw)
+    P, Q, ub, ib = orc.init_model(m.rows, m.cols, 100)
+    log = orc.train(_as_orc(m), _as_orc(te), ocfg, P, Q, ub, ib, m.global_bias, dot_order=orc.DOT_TREE16,
+                    acc=orc.ACC_F64, schedule=orc.SCHED_PATIENCE)
+    assert cu.lib().cu2rec_hogwild_resident(-1) == AUTO
+    gP, gQ, losses, gub, gib = cu.train(m, te, cfg, mode="hogwild", verbose=False)
+    assert [e["iteration"] for e in log] == [1, 4, 8, 12]  # training.cu:118
+    np.testing.assert_array_equal(gP, P)
+    np.testing.assert_array_equal(gQ, Q)
+    np.testing.assert_array_equal(gub, ub)
+    np.testing.assert_array_equal(gib, ib)
+    for e in log:
+        assert losses[e["iteration"] - 1] == e["test_rmse"]
+    assert cfg.learning_rate == ocfg.learning_rate and cfg.cur_iterations == 12
