@@ -1,5 +1,5 @@
 // Resident Hogwild SGD for gfx950: the reference's per-iteration launches (training.cu:107-113, sgd_update
-// sgd.cu:22-75) folded into ONE persistent launch that keeps every user's factor row in the register file.
+// sgd.cu:22-75) folded into ONE persistent launch that keeps every user's factor row in the register file (and, beyond that, the LDS).
 //
 // Why: in the streaming kernel (kernels.hip, sgd_hogwild_kernel) half of the 16 f + 32 algorithmic bytes per
 // update are the user's own row going to HBM and back between two launches, although nobody else ever
@@ -49,7 +49,7 @@
 
 #ifndef CU2REC_RES_ABLATE
 #define CU2REC_RES_ABLATE 0  // timing-only builds (tools/build_variant.sh), bits: 1 no grid barrier, 2 no updates, 4 no item-row
-                             // stores, 8 no item-row loads; never set in the shipped library
+                             // stores; never set in the shipped library
 #endif
 
 #ifndef CU2REC_RES_NT_PAIRS
@@ -216,13 +216,32 @@ __device__ __forceinline__ float predict_wrapped(const Row<J> &p, const Row<J> &
 // per iteration); early exits out of an unrolled chain made the register allocator spill hundreds of registers
 // instead.  So: a few R per row width are compiled, the host rounds the count it needs up to the next one and
 // shrinks the grid to match; frozen items (update_items == 0) take the streaming kernel, which needs no barrier.
-template <int J, int RMAX, int D>
+//
+// RL of a group's R rows live in the CU's LDS instead of registers (the last RL): 32 groups x RL rows x J x 256 B per
+// workgroup, each lane reading and writing its own 16 bytes (conflict free).  Such a row is read at the start of its
+// step and written back at the end; everything else is the same.  With the 160 KB of LDS a CU holds 9 more rows per
+// group at f <= 128 (26 instead of 17: 213,000 users on 256 CUs).
+template <int J, int RMAX, int D, int RL>
 __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, ResidentArgs ra) {
     constexpr bool UPD = true;
     constexpr int R = RMAX;
-    static_assert(D >= 1 && D <= RMAX, "pipeline depth");
+    constexpr int RREG = R - RL;  // rows in registers
+    static_assert(D >= 1 && D <= RMAX && RL >= 0 && RREG >= 1, "shape");
+    static_assert(sizeof(float4) * kResGroups * RL * J * kGroup + 64 <= 160 * 1024, "LDS rows exceed the CU's 160 KB");
     constexpr int M = (RMAX + kGroup - 1) / kGroup;  // lane-distributed scalar sets
     __shared__ BarrierShared s_barrier;
+    __shared__ float4 s_rows[RL > 0 ? kResGroups * RL * J * kGroup : 1];
+    float4 *my_lds = s_rows + (threadIdx.x / kGroup) * (RL * J * kGroup) + (threadIdx.x & (kGroup - 1));
+    auto lds_load = [&](int rl) {
+        Row<J> row;
+#pragma unroll
+        for (int j = 0; j < J; ++j) row.v[j] = my_lds[(rl * J + j) * kGroup];
+        return row;
+    };
+    auto lds_store = [&](int rl, const Row<J> &row) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) my_lds[(rl * J + j) * kGroup] = row.v[j];
+    };
     const int lane = threadIdx.x & (kGroup - 1);
     const int group = blockIdx.x * kResGroups + (threadIdx.x / kGroup);
     const int n_groups = gridDim.x * kResGroups;
@@ -248,16 +267,19 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
         my_n[m] = valid ? a.indptr[x + 1] - my_low[m] : 0;  // 0: no ratings, skipped (sgd.cu:34)
         my_ub[m] = valid ? a.user_bias[x] : 0.f;
     }
-    Row<J> p[RMAX];
+    Row<J> p[RREG];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int x = group + r * n_groups;
-        if (r < R && x < a.n_rows) {
-            p[r] = load_wrapped<J>(a.P + static_cast<size_t>(x) * a.ldp, sl);
+        Row<J> row;
+        if (x < a.n_rows) {
+            row = load_wrapped<J>(a.P + static_cast<size_t>(x) * a.ldp, sl);
         } else {
 #pragma unroll
-            for (int j = 0; j < J; ++j) p[r].v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < J; ++j) row.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (r < RREG) p[r] = row;
+        else lds_store(r - RREG, row);
     }
 
     // sample of iteration `it` for the 16 users of every set: one draw + one gather per lane (sgd.cu:36-44)
@@ -314,13 +336,8 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
         q_item[s] = __shfl(item[set], src, kGroup);  // 0 for a user without ratings
         q_rating[s] = __shfl(rating[set], src, kGroup);
         q_active[s] = __shfl(my_n[set], src, kGroup) > 0;
-        if (!(CU2REC_RES_ABLATE & 8)) {
-            q[s] = load_wrapped<J>(a.Q + static_cast<size_t>(q_item[s]) * a.ldq, sl);
-            q_ib[s] = a.item_bias[q_item[s]];
-        } else {
-            q[s] = p[0];
-            q_ib[s] = 0.f;
-        }
+        q[s] = load_wrapped<J>(a.Q + static_cast<size_t>(q_item[s]) * a.ldq, sl);
+        q_ib[s] = a.item_bias[q_item[s]];
     };
     auto consume = [&](Row<J> &pc, int c, int s) {
         const int set = c / kGroup, src = c % kGroup;
@@ -355,7 +372,16 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
         if (!(CU2REC_RES_ABLATE & 2)) {
 #pragma unroll
             for (int r = 0; r < R + D; ++r) {
-                if (r >= D) consume(p[r - D], r - D, (r - D) % D);
+                if (r >= D) {
+                    const int c = r - D;
+                    if (c < RREG) {
+                        consume(p[c < RREG ? c : 0], c, c % D);
+                    } else {  // an LDS row: in, one update, out
+                        Row<J> row = lds_load(c - RREG);
+                        consume(row, c, c % D);
+                        lds_store(c - RREG, row);
+                    }
+                }
                 if (r < R) issue(r, r % D);
                 // keep a step's shuffles and address arithmetic inside the step: hoisted to the top of the
                 // straight-line code they cost ~10 live registers per user, which the resident rows need
@@ -377,10 +403,11 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
     float *P_out = a.P;
     asm volatile("" : "+s"(P_out));
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int x = group + r * n_groups;
         const bool has_ratings = __shfl(my_n[r / kGroup], r % kGroup, kGroup) > 0;
-        if (r < R && x < a.n_rows && has_ratings) store_wrapped<J>(P_out + static_cast<size_t>(x) * a.ldp, sl, p[r]);
+        const Row<J> row = r < RREG ? p[r < RREG ? r : 0] : lds_load(r - RREG);
+        if (x < a.n_rows && has_ratings) store_wrapped<J>(P_out + static_cast<size_t>(x) * a.ldp, sl, row);
     }
 #pragma unroll
     for (int m = 0; m < M; ++m)
@@ -390,22 +417,31 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
 // ---- host side --------------------------------------------------------------------------------------
 
 // Compiled (J, R) variants.  J = float4 slots per lane (row width), R = users per group: what fits 256 VGPRs without
-// spilling (f <= 64: 262,000 users; f <= 128: 147,000; f <= 192: 65,000; f <= 256: 49,000 on 256 CUs).
+// spilling, plus (the _LDS variants) what the CU's 160 KB of LDS adds.  Capacity on 256 CUs: f <= 64: 385,000 users,
+// f <= 128: 204,000, f <= 192: 114,000, f <= 256: 81,000.
 struct Variant {
     int j, r;
     const void *kernel;
 };
-#define CU2REC_RES_VARIANT(J, R, D) {J, R, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D>)}
+#define CU2REC_RES_VARIANT(J, R, D) {J, R, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, 0>)}
+#define CU2REC_RES_VARIANT_LDS(J, R, D, RL) {J, R, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, RL>)}
 const Variant kVariants[] = {
     CU2REC_RES_VARIANT(1, 4, 4),   CU2REC_RES_VARIANT(1, 8, 4),   CU2REC_RES_VARIANT(1, 12, 4),  CU2REC_RES_VARIANT(1, 16, 4),
     CU2REC_RES_VARIANT(1, 20, 4),  CU2REC_RES_VARIANT(1, 24, 4),  CU2REC_RES_VARIANT(1, 28, 4),  CU2REC_RES_VARIANT(1, 32, 4),
+    CU2REC_RES_VARIANT_LDS(1, 36, 4, 8), CU2REC_RES_VARIANT_LDS(1, 40, 4, 12), CU2REC_RES_VARIANT_LDS(1, 44, 4, 16),
+    CU2REC_RES_VARIANT_LDS(1, 47, 4, 19),
     CU2REC_RES_VARIANT(2, 4, CU2REC_RES_D2),  CU2REC_RES_VARIANT(2, 6, CU2REC_RES_D2),  CU2REC_RES_VARIANT(2, 8, CU2REC_RES_D2),
     CU2REC_RES_VARIANT(2, 10, CU2REC_RES_D2), CU2REC_RES_VARIANT(2, 12, CU2REC_RES_D2), CU2REC_RES_VARIANT(2, 14, CU2REC_RES_D2),
     CU2REC_RES_VARIANT(2, 16, CU2REC_RES_D2), CU2REC_RES_VARIANT(2, 17, CU2REC_RES_D2), CU2REC_RES_VARIANT(2, 18, CU2REC_RES_D2),
+    CU2REC_RES_VARIANT_LDS(2, 20, CU2REC_RES_D2, 4), CU2REC_RES_VARIANT_LDS(2, 22, CU2REC_RES_D2, 6),
+    CU2REC_RES_VARIANT_LDS(2, 24, CU2REC_RES_D2, 8), CU2REC_RES_VARIANT_LDS(2, 25, CU2REC_RES_D2, 9),
     CU2REC_RES_VARIANT(3, 4, 3),   CU2REC_RES_VARIANT(3, 6, 3),   CU2REC_RES_VARIANT(3, 8, 3),
+    CU2REC_RES_VARIANT_LDS(3, 10, 3, 2), CU2REC_RES_VARIANT_LDS(3, 12, 3, 4), CU2REC_RES_VARIANT_LDS(3, 14, 3, 6),
     CU2REC_RES_VARIANT(4, 4, 2),   CU2REC_RES_VARIANT(4, 6, 2),
+    CU2REC_RES_VARIANT_LDS(4, 8, 2, 2), CU2REC_RES_VARIANT_LDS(4, 10, 2, 4),
 };
 #undef CU2REC_RES_VARIANT
+#undef CU2REC_RES_VARIANT_LDS
 constexpr int kNumVariants = static_cast<int>(sizeof(kVariants) / sizeof(kVariants[0]));
 
 // smallest compiled variant with this J and at least `need` users per group; -1 if none

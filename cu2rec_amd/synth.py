@@ -18,6 +18,8 @@ SHAPES = {
     "ml-1m": (6040, 3706, 1_000_209, 20),
     "ml-20m": (138_493, 26_744, 20_000_263, 20),
     "netflix": (480_189, 17_770, 100_480_507, 1),
+    # not a reference experiment: the next MovieLens size up, 20 user rows per group (4 of them in LDS) in resident launches
+    "ml-25m": (162_541, 59_047, 25_000_095, 20),
 }
 
 

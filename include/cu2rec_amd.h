@@ -189,7 +189,7 @@ int cu2rec_hogwild_iters_per_launch(int k);
  * launch per cu2rec_sgd_update call).  The iterations of a call keep the reference's cadence -- every user's update
  * of iteration i is visible to iteration i+1 -- but the boundary between them is a grid-wide barrier instead of a
  * kernel boundary, and every user's row stays in the register file for the whole call (no P traffic between
- * iterations).  Applies when all user rows of the CSR fit the register file (e.g. 147,000 users at f <= 128) and
+ * iterations).  Applies when all user rows of the CSR fit the register file + LDS (e.g. 204,000 users at f <= 128) and
  * hogwild_iters_per_launch is 1; otherwise the call runs one streaming launch per iteration as before.
  * policy: 0 never, 1 auto (default: when it fits and a call covers >= 4 iterations), 2 whenever it fits;
  * CU2REC_RESIDENT=0|1|2 in the environment sets the initial value.  Returns the previous policy; other values query.

@@ -110,11 +110,15 @@ def test_resident_auto_policy_and_chunked_calls(ml20m_like):
     _run_and_compare(ml20m_like, 100, 0, 12, AUTO, chunks=[5, 4, 3])
 
 
-@pytest.mark.parametrize("f,users", [(50, 40000), (64, 9000), (128, 147000), (160, 30000), (256, 20000), (8, 700)])
+@pytest.mark.parametrize("f,users", [(50, 40000), (64, 9000), (128, 147000), (160, 30000), (256, 20000), (8, 700),
+                                     (100, 200000), (50, 300000), (160, 80000), (256, 64000)])
 def test_resident_every_row_width(f, users):
     """J = 1..4 float4 slots per lane, few and many users per group (147,000 users at f = 128 is the 18 per group the
-    registers hold), a grid smaller than the chip (700 users), resume from a non-zero iteration."""
+    registers hold; 200,000 users at f = 100 need 25 per group, 9 of them in LDS; likewise the last three cases), a
+    grid smaller than the chip (700 users), resume from a non-zero iteration."""
     m = _collision_free_set(users, 2 * users + 64, 4, 7, 6, seed=f, empty_every=0 if users < 1000 else 41)
+    with resident_policy(FORCE):
+        assert cu.lib().cu2rec_hogwild_resident_plan(users, f, 6, None, None) == 1
     _run_and_compare(m, f, 7, 6, FORCE)
 
 
