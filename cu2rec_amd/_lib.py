@@ -77,6 +77,9 @@ SIGNATURES = {
     "cu2rec_sgd_update_ex": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,
                                        C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                        _P]),
+    "cu2rec_sgd_update_pingpong": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P,
+                                             C.c_float, C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, _ip, _P]),
     "cu2rec_sample_pairs_bytes": (C.c_size_t, [C.c_int]),
     "cu2rec_sample_pairs_build": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "cu2rec_hogwild_iters_per_launch": (C.c_int, [C.c_int]),

@@ -12,8 +12,8 @@ import numpy as np
 
 from ._lib import Config, Cu2recError, Hyper, TrainStats, check, lib
 
-SGD_HOGWILD, SGD_SERIAL, SGD_ORDERED = 0, 1, 2
-MODES = {"hogwild": SGD_HOGWILD, "serial": SGD_SERIAL, "ordered": SGD_ORDERED}
+SGD_HOGWILD, SGD_SERIAL, SGD_ORDERED, SGD_PINGPONG = 0, 1, 2, 3
+MODES = {"hogwild": SGD_HOGWILD, "serial": SGD_SERIAL, "ordered": SGD_ORDERED, "pingpong": SGD_PINGPONG}
 
 
 def _mode(mode):

@@ -117,6 +117,37 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
     CU2REC_HIP(hipGetLastError());
 }
 
+bool sgd_update_pingpong(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P,
+                         int ldp, float *Q, float *Q_target, int ldq, float *user_bias, float *item_bias,
+                         float *item_bias_target, unsigned long long *claim, float global_bias, int n_factors,
+                         const cu2rec_hyper &hyper, uint64_t seed, uint64_t iter0, int n_iters, int update_items,
+                         int user_offset, bool swap_last, hipStream_t stream) {
+    require(n_iters >= 0, "cu2rec_sgd_update_pingpong: bad iteration count");
+    require(Q_target && item_bias_target && claim, "cu2rec_sgd_update_pingpong: null device pointer");
+    check_aligned(Q_target, "Q_target");
+    SgdArgs a = make_sgd_args(indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias, global_bias,
+                              n_factors, hyper, seed, update_items, user_offset);
+    if (n_rows == 0 || n_iters == 0) return false;
+    require_device();
+    resident_check_fault();
+    // claims carry the iteration number; a call may restart from an earlier one, so they start from "nobody"
+    CU2REC_HIP(hipMemsetAsync(claim, 0xFF, static_cast<size_t>(std::max(n_cols, 1)) * sizeof(unsigned long long), stream));
+    PingPongArgs pp{Q_target, item_bias_target, claim};
+    a.iters = 1;
+    bool swapped = false;
+    for (int i = 0; i < n_iters; ++i) {  // one claim + one update launch per iteration (training.cu:107-113)
+        a.iter0 = iter0 + static_cast<uint64_t>(i);
+        launch_sgd_pingpong(a, pp, stream);
+        if (i + 1 < n_iters || swap_last) {  // training.cu:164-165
+            std::swap(a.Q, pp.Q_target);
+            std::swap(a.item_bias, pp.item_bias_target);
+            swapped = !swapped;
+        }
+    }
+    CU2REC_HIP(hipGetLastError());
+    return swapped;
+}
+
 void sample_pairs_build(const int *indices, const float *data, int nnz, void *pairs, hipStream_t stream) {
     require(nnz >= 0, "cu2rec_sample_pairs_build: bad size");
     if (nnz == 0) return;
@@ -276,6 +307,7 @@ DeviceModel::DeviceModel(int rows_, int cols_, int f_, const float *hP, const fl
 }
 
 void DeviceModel::download(float *hP, float *hQ, float *hub, float *hib) const {
+    require(!swap_pending, "cu2rec_model_download: a ping-pong swap is pending (finish_swap)");
     CU2REC_HIP(hipDeviceSynchronize());
     resident_check_fault();
     if (hP) download_padded(P, hP, rows, n_factors, ld);
@@ -284,9 +316,41 @@ void DeviceModel::download(float *hP, float *hQ, float *hub, float *hib) const {
     if (hib && cols) item_bias.download(hib, cols);
 }
 
+void DeviceModel::finish_swap() {
+    if (!swap_pending) return;
+    Q.swap(Q_other);
+    item_bias.swap(item_bias_other);
+    swap_pending = false;
+}
+
 void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t seed, uint64_t iter0, int n_iters, int mode,
-                      int update_items, hipStream_t stream) {
+                      int update_items, hipStream_t stream, bool defer_last_swap) {
     require(train.rows <= rows && train.max_item < cols, "cu2rec_model_sgd: ratings exceed the model's shape");
+    finish_swap();
+    if (mode == CU2REC_SGD_PINGPONG) {
+        if (!Q_other.ptr) {
+            Q_other.allocate(Q.count);
+            item_bias_other.allocate(item_bias.count);
+            claim.allocate(std::max(cols, 1));
+        }
+        if (!other_in_sync) {  // training.cu:37,69-70: the targets start as copies of Q / item_bias
+            CU2REC_HIP(hipMemcpyAsync(Q_other.ptr, Q.ptr, Q.count * sizeof(float), hipMemcpyDeviceToDevice, stream));
+            CU2REC_HIP(hipMemcpyAsync(item_bias_other.ptr, item_bias.ptr, item_bias.count * sizeof(float),
+                                      hipMemcpyDeviceToDevice, stream));
+            other_in_sync = true;
+        }
+        const bool swapped = sgd_update_pingpong(train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr,
+                                                 ld, Q.ptr, Q_other.ptr, ld, user_bias.ptr, item_bias.ptr,
+                                                 item_bias_other.ptr, claim.ptr, global_bias, n_factors, h, seed, iter0,
+                                                 n_iters, update_items, 0, !defer_last_swap, stream);
+        if (swapped) {  // Q / item_bias always name the current item side
+            Q.swap(Q_other);
+            item_bias.swap(item_bias_other);
+        }
+        swap_pending = defer_last_swap && n_iters > 0 && train.rows > 0;
+        return;
+    }
+    other_in_sync = false;  // another mode moves Q on without the second pair
     if (mode == CU2REC_SGD_ORDERED) {
         if (!train.schedule)
             train.schedule.reset(new OrderedSchedule(train.indptr.ptr, train.indices.ptr, train.rows, cols, train.nnz));
@@ -389,6 +453,21 @@ size_t cu2rec_sample_pairs_bytes(int nnz) { return nnz > 0 ? static_cast<size_t>
 
 int cu2rec_sample_pairs_build(const int *indices, const float *data, int nnz, void *pairs, void *stream) {
     return guarded([&] { sample_pairs_build(indices, data, nnz, pairs, as_stream(stream)); });
+}
+
+int cu2rec_sgd_update_pingpong(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols,
+                               float *P, int ldp, float *Q, float *Q_target, int ldq, float *user_bias,
+                               float *item_bias, float *item_bias_target, unsigned long long *claim,
+                               float global_bias, int n_factors, const cu2rec_hyper *hyper, uint64_t seed,
+                               uint64_t iter0, int n_iters, int update_items, int user_offset, int swap_last,
+                               int *swapped, void *stream) {
+    return guarded([&] {
+        require(hyper, "cu2rec_sgd_update_pingpong: hyper is null");
+        const bool s = sgd_update_pingpong(indptr, indices, data, n_rows, n_cols, P, ldp, Q, Q_target, ldq, user_bias,
+                                           item_bias, item_bias_target, claim, global_bias, n_factors, *hyper, seed, iter0,
+                                           n_iters, update_items, user_offset, swap_last != 0, as_stream(stream));
+        if (swapped) *swapped = s ? 1 : 0;
+    });
 }
 
 int cu2rec_hogwild_iters_per_launch(int k) {

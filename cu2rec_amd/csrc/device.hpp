@@ -25,6 +25,14 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
                 const cu2rec_hyper &hyper, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
                 int user_offset, hipStream_t stream, const void *sample_pairs = nullptr);
 
+// CU2REC_SGD_PINGPONG on raw pointers (include/cu2rec_amd.h: cu2rec_sgd_update_pingpong); returns true if the item
+// side's current values ended up in Q_target / item_bias_target (odd number of swaps)
+bool sgd_update_pingpong(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols, float *P,
+                         int ldp, float *Q, float *Q_target, int ldq, float *user_bias, float *item_bias,
+                         float *item_bias_target, unsigned long long *claim, float global_bias, int n_factors,
+                         const cu2rec_hyper &hyper, uint64_t seed, uint64_t iter0, int n_iters, int update_items,
+                         int user_offset, bool swap_last, hipStream_t stream);
+
 // [nnz] x {item, rating} side by side for SgdArgs::pairs (8 bytes per rating, device memory)
 void sample_pairs_build(const int *indices, const float *data, int nnz, void *pairs, hipStream_t stream);
 
@@ -57,11 +65,17 @@ struct DeviceModel {
     DeviceModel(int rows, int cols, int n_factors, const float *P, const float *Q, const float *user_bias,
                 const float *item_bias, float global_bias);
     void download(float *P, float *Q, float *user_bias, float *item_bias) const;
+    // defer_last_swap (CU2REC_SGD_PINGPONG only): leave out the last iteration's swap; finish_swap() does it later
     void sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t seed, uint64_t iter0, int n_iters, int mode,
-             int update_items, hipStream_t stream);
+             int update_items, hipStream_t stream, bool defer_last_swap = false);
+    void finish_swap();
     void loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq, float *mae, float *rmse,
               hipStream_t stream) const;
     DeviceBuffer<float> P, Q, user_bias, item_bias;
+    DeviceBuffer<float> Q_other, item_bias_other;  // CU2REC_SGD_PINGPONG: the second buffer pair, created on first use
+    DeviceBuffer<unsigned long long> claim;
+    bool other_in_sync = false;   // Q_other / item_bias_other were last written by the ping-pong mode itself
+    bool swap_pending = false;
     mutable DeviceBuffer<double> workspace;
     int rows, cols, n_factors, ld;
     float global_bias;

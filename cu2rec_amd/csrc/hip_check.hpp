@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <sstream>
+#include <utility>
 
 #include "common.hpp"
 
@@ -52,6 +53,10 @@ struct DeviceBuffer {  // RAII hipMalloc, the role of CudaDenseMatrix / CudaCSRM
     void download(T *host, size_t n) const { CU2REC_HIP(hipMemcpy(host, ptr, n * sizeof(T), hipMemcpyDeviceToHost)); }
     void zero() {
         if (count) CU2REC_HIP(hipMemset(ptr, 0, count * sizeof(T)));
+    }
+    void swap(DeviceBuffer &other) {
+        std::swap(ptr, other.ptr);
+        std::swap(count, other.count);
     }
 };
 

@@ -13,6 +13,7 @@
 //
 // What each kernel replaces in the reference (matrix_factorization/):
 //   sgd_hogwild_kernel / sgd_serial_kernel  sgd_update       sgd.cu:22-75   (+ initCurand :11-16: gone)
+//   pingpong_claim_kernel + sgd_pingpong_kernel   sgd_update with its Q_target / item_is_updated semantics kept
 //   loss_fused_kernel                       loss_kernel      loss.cu:19-35  + total_loss_kernel<B> :58-128 (x2)
 //   error_metrics_kernel                    total_loss_kernel<B>  loss.cu:58-128 on an explicit array
 //   items_delta_*                           (new: multi-GPU item-factor exchange)
@@ -106,6 +107,51 @@ __global__ __launch_bounds__(64) void sgd_serial_kernel(SgdArgs a) {
             store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
             if (lane == 0) a.user_bias[x] = ub;
             __threadfence();  // the next user may read the item row this one just wrote
+        }
+    }
+}
+
+// ---- SGD, the reference GPU kernel's own semantics (CU2REC_SGD_PINGPONG): sgd.cu:22-75 -------------------------
+// Who is the "early bird" of an item (sgd.cu:49-50)?  The reference races on a bool; here every user claims its item
+// with a 64-bit atomicMin of (~iteration << 32 | thread index): newer iterations beat the leftovers of older ones (no
+// per-iteration memset, training.cu:168), and inside an iteration the lowest thread index wins.  Thread gid handles
+// user (gid + start_user) % rows with start_user = 250 * iteration (training.cu:97-98,115).
+__device__ __forceinline__ unsigned long long pingpong_key(uint64_t it, int x, int n_rows) {
+    const int start_user = static_cast<int>((250u * it) % static_cast<uint64_t>(n_rows));
+    const int gid = x >= start_user ? x - start_user : x - start_user + n_rows;
+    return (static_cast<unsigned long long>(~static_cast<uint32_t>(it)) << 32) | static_cast<unsigned>(gid);
+}
+
+__global__ __launch_bounds__(kBlock) void pingpong_claim_kernel(SgdArgs a, PingPongArgs pp) {
+    for (int x = blockIdx.x * kBlock + threadIdx.x; x < a.n_rows; x += gridDim.x * kBlock) {
+        const int low = a.indptr[x], high = a.indptr[x + 1];
+        if (low == high) continue;
+        const int y = a.indices[sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + x), a.iter0, low, high)];
+        atomicMin(&pp.claim[y], pingpong_key(a.iter0, x, a.n_rows));
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(kBlock) void sgd_pingpong_kernel(SgdArgs a, PingPongArgs pp) {
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int group = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
+    const int n_groups = gridDim.x * kGroupsPerBlock;
+    for (int x = group; x < a.n_rows; x += n_groups) {
+        const int low = a.indptr[x], high = a.indptr[x + 1];
+        if (low == high) continue;  // sgd.cu:34
+        const int y_i = sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + x), a.iter0, low, high);  // sgd.cu:36-37
+        const int y = a.indices[y_i];
+        Row<J> p = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+        Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);  // nobody writes a.Q in this launch
+        const float ub = a.user_bias[x], ib = a.item_bias[y];
+        const float err = a.data[y_i] - predict<J>(p, q, ub, ib, a.global_bias);  // sgd.cu:45
+        const bool early_bird = pp.claim[y] == pingpong_key(a.iter0, x, a.n_rows);  // sgd.cu:49-50
+        rank1_update<J>(p, q, err, a.h);                                            // sgd.cu:53-64
+        store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
+        if (lane == 0) a.user_bias[x] = ub + a.h.lr * (err - a.h.ub_reg * ub);  // sgd.cu:67
+        if (a.update_items && early_bird) {                                     // sgd.cu:61,70
+            store_row<J>(pp.Q_target, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
+            if (lane == 0) pp.item_bias_target[y] = ib + a.h.lr * (err - a.h.ib_reg * ib);  // sgd.cu:71
         }
     }
 }
@@ -301,6 +347,12 @@ void launch_sgd_j(const SgdArgs &a, int mode, hipStream_t stream) {
 }
 
 template <int J>
+void launch_pingpong_j(const SgdArgs &a, const PingPongArgs &pp, hipStream_t stream) {
+    const int blocks = blocks_for(static_cast<size_t>(a.n_rows), kGroupsPerBlock, 1 << 20);
+    hipLaunchKernelGGL(sgd_pingpong_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, pp);
+}
+
+template <int J>
 void launch_loss_j(const LossArgs &a, int blocks, hipStream_t stream) {
     hipLaunchKernelGGL(loss_fused_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a);
 }
@@ -319,6 +371,22 @@ void launch_sgd(const SgdArgs &a, int mode, hipStream_t stream) {
         case 6: launch_sgd_j<6>(a, mode, stream); break;
         case 7: launch_sgd_j<7>(a, mode, stream); break;
         case 8: launch_sgd_j<8>(a, mode, stream); break;
+        default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
+    }
+}
+
+void launch_sgd_pingpong(const SgdArgs &a, const PingPongArgs &pp, hipStream_t stream) {
+    hipLaunchKernelGGL(pingpong_claim_kernel, dim3(blocks_for(static_cast<size_t>(a.n_rows), kBlock, 4096)), dim3(kBlock), 0,
+                       stream, a, pp);
+    switch (slots_per_lane(a.nslots)) {
+        case 1: launch_pingpong_j<1>(a, pp, stream); break;
+        case 2: launch_pingpong_j<2>(a, pp, stream); break;
+        case 3: launch_pingpong_j<3>(a, pp, stream); break;
+        case 4: launch_pingpong_j<4>(a, pp, stream); break;
+        case 5: launch_pingpong_j<5>(a, pp, stream); break;
+        case 6: launch_pingpong_j<6>(a, pp, stream); break;
+        case 7: launch_pingpong_j<7>(a, pp, stream); break;
+        case 8: launch_pingpong_j<8>(a, pp, stream); break;
         default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
     }
 }

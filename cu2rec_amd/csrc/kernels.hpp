@@ -55,10 +55,20 @@ struct LossArgs {
     double *partials;     // [2 * blocks]: per block {sum |e|, sum e^2}
 };
 
+// CU2REC_SGD_PINGPONG: the second item-side buffer pair and the first-writer claims (sgd.cu:22-75's Q_target,
+// item_bias_target, item_is_updated)
+struct PingPongArgs {
+    float *Q_target;
+    float *item_bias_target;
+    unsigned long long *claim;  // [n_cols]: (~iteration << 32 | thread index) of the first claimant, by atomicMin
+};
+
 constexpr int kMaxPartialBlocks = 4096;
 
 int slots_per_lane(int nslots);
 void launch_sgd(const SgdArgs &args, int mode, hipStream_t stream);
+// one iteration (args.iter0) of CU2REC_SGD_PINGPONG: claim kernel + update kernel; args.Q / item_bias are only read
+void launch_sgd_pingpong(const SgdArgs &args, const PingPongArgs &pp, hipStream_t stream);
 int loss_blocks(int nnz);
 void launch_loss(const LossArgs &args, int blocks, hipStream_t stream);
 int error_metrics_blocks(int n);

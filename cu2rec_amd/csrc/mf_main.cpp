@@ -2,7 +2,7 @@
 // Drop-in for the reference CLI (mf.cu:16-99): same arguments, same stdout lines, same output
 // files; built on the C ABI of libcu2rec_amd.
 //
-//   bin/mf [-c config] [-m hogwild|serial] train.csv test.csv
+//   bin/mf [-c config] [-m hogwild|ordered|serial|pingpong] train.csv test.csv
 #include <getopt.h>
 #include <hip/hip_runtime_api.h>
 
@@ -27,6 +27,7 @@ int main(int argc, char **argv) {
             case 'm':
                 mode = std::strcmp(optarg, "serial") == 0    ? CU2REC_SGD_SERIAL
                        : std::strcmp(optarg, "ordered") == 0 ? CU2REC_SGD_ORDERED
+                       : std::strcmp(optarg, "pingpong") == 0 ? CU2REC_SGD_PINGPONG
                                                              : CU2REC_SGD_HOGWILD;
                 break;
             default:
@@ -35,7 +36,7 @@ int main(int argc, char **argv) {
         }
     }
     if (optind + 2 > argc) {
-        std::cerr << "usage: mf [-c config] [-m hogwild|serial] train.csv test.csv\n";
+        std::cerr << "usage: mf [-c config] [-m hogwild|ordered|serial|pingpong] train.csv test.csv\n";
         return -1;
     }
     try {

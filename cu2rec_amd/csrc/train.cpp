@@ -2,7 +2,8 @@
 // Same observable schedule -- loss cadence, stdout lines, patience / learning-rate decay, what
 // the clock covers -- with the SGD launches between two loss checks queued back to back on one
 // stream and timed by HIP events.  No ping-pong buffers, no per-iteration memset, no RNG state:
-// item rows are updated in place (mf_sequential.cu semantics, the parity target).
+// item rows are updated in place (mf_sequential.cu semantics, the parity target) -- except in
+// CU2REC_SGD_PINGPONG, which keeps the reference GPU loop's two item buffers and its loss-before-swap order.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -61,7 +62,10 @@ void train(const DeviceCsr &train_csr, const DeviceCsr &test_csr, cu2rec_config 
         const int n = seg_end - i + 1;
         const cu2rec_hyper h{cfg.learning_rate, cfg.P_reg, cfg.Q_reg, cfg.user_bias_reg, cfg.item_bias_reg};
         CU2REC_HIP(hipEventRecord(ev.start, stream));
-        model.sgd(train_csr, h, seed, iter_base + static_cast<uint64_t>(i), n, mode, cfg.is_train, stream);
+        // CU2REC_SGD_PINGPONG: the reference evaluates the loss BEFORE it swaps the item buffers (training.cu:121 vs
+        // :164), i.e. on this iteration's P and the item side the iteration READ; so the last swap waits for the loss
+        model.sgd(train_csr, h, seed, iter_base + static_cast<uint64_t>(i), n, mode, cfg.is_train, stream,
+                  /*defer_last_swap=*/mode == CU2REC_SGD_PINGPONG);
         CU2REC_HIP(hipEventRecord(ev.stop, stream));
 
         // training.cu:121-137: loss on train then test, printed in the reference's format
@@ -83,6 +87,7 @@ void train(const DeviceCsr &train_csr, const DeviceCsr &test_csr, cu2rec_config 
             cfg.learning_rate *= cfg.learning_rate_decay;
             if (verbose) std::printf("New Learning Rate: %f\n: ", cfg.learning_rate);
         }
+        model.finish_swap();                             // training.cu:164-165 (no-op outside CU2REC_SGD_PINGPONG)
         if (losses) losses[seg_end] = validation_rmse;  // training.cu:158
         cfg.cur_iterations += n;                         // training.cu:170
         i = seg_end + 1;

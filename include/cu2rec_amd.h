@@ -151,7 +151,17 @@ typedef enum cu2rec_sgd_mode {
      * ascending user order with the item row held in registers (cu2rec_amd/csrc/ordered.hip).
      * Bit-identical to CU2REC_SGD_SERIAL and to the CPU oracle.  Needs a cu2rec_schedule workspace
      * (the object layer creates one per cu2rec_csr on first use). */
-    CU2REC_SGD_ORDERED = 2
+    CU2REC_SGD_ORDERED = 2,
+    /* The reference GPU kernel's OWN semantics (sgd.cu:22-75 with the loop of training.cu:107-171), for callers that
+     * want those trajectories rather than mf_sequential.cu's: every user reads the item side as it was at the start
+     * of the iteration, the FIRST user to claim an item (sgd.cu:49-50) writes its new row / bias into a second buffer
+     * pair, the pairs swap after every iteration (training.cu:164-165), an item nobody sampled falls back to its value
+     * of two iterations ago.  "First" -- a race on a non-atomic flag in the reference -- is the lowest thread index
+     * here (thread gid handles user (gid + 250 * iteration) % rows, training.cu:97-98,115), decided with a 64-bit
+     * atomicMin, so the mode is deterministic and race free; the reference's surplus threads (grid = rows / n_threads
+     * + 1 blocks, which update a few users twice) are not reproduced.  Object layer only (cu2rec_model_sgd,
+     * cu2rec_train, bin/mf -m pingpong) or cu2rec_sgd_update_pingpong below. */
+    CU2REC_SGD_PINGPONG = 3
 } cu2rec_sgd_mode;
 
 /* Replaces sgd_update (sgd.cu:22-75) + the per-iteration launch loop of train()
@@ -163,6 +173,20 @@ int cu2rec_sgd_update(const int *indptr, const int *indices, const float *data, 
                       float *P, int ldp, float *Q, int ldq, float *user_bias, float *item_bias, float global_bias,
                       int n_factors, const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters,
                       int mode, int update_items, int user_offset, void *stream);
+
+/* sgd_update (sgd.h:12-16) with its Q_target / item_bias_target / item_is_updated arguments, n_iters iterations with the
+ * swap of training.cu:164-165 after each one: CU2REC_SGD_PINGPONG on raw device pointers.  Q_target / item_bias_target:
+ * second buffers of the same shapes, initialised by the caller as copies of Q / item_bias (training.cu:37,69-70);
+ * claim: n_cols 64-bit words of workspace (the role of item_is_updated; no per-iteration memset, reset by the call).
+ * The buffers swap ROLES like the reference's pointers: *swapped = 1 means the current item side is now in
+ * Q_target / item_bias_target (an odd number of swaps).  swap_last == 0 leaves out the last iteration's swap, so that
+ * a loss evaluated right after the call sees what the reference's does (training.cu:121-137 run before the swap). */
+int cu2rec_sgd_update_pingpong(const int *indptr, const int *indices, const float *data, int n_rows, int n_cols,
+                               float *P, int ldp, float *Q, float *Q_target, int ldq, float *user_bias,
+                               float *item_bias, float *item_bias_target, unsigned long long *claim,
+                               float global_bias, int n_factors, const cu2rec_hyper *hyper, uint64_t seed,
+                               uint64_t iter0, int n_iters, int update_items, int user_offset, int swap_last,
+                               int *swapped, void *stream);
 
 /* Optional sample array for the Hogwild path: [nnz] x {int32 item, float32 rating} = indices[k] and data[k] of the
  * CSR side by side (8 bytes per rating, device memory, 8-byte aligned), so that drawing a rating (sgd.cu:36-44) is

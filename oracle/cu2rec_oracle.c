@@ -300,6 +300,55 @@ void orc_sgd_iterations(const int *indptr, const int *indices, const float *data
                         iter0 + (uint64_t)i, dot_order, update_items);
 }
 
+void orc_pingpong_swap(float *Q, float *Q_target, float *item_bias, float *item_bias_target, int cols, int f) {
+    /* training.cu:164-165 swaps pointers; the caller's arrays keep their roles here, so exchange the contents */
+    for (size_t k = 0; k < (size_t)cols * f; ++k) {
+        const float t = Q[k];
+        Q[k] = Q_target[k];
+        Q_target[k] = t;
+    }
+    for (int y = 0; y < cols; ++y) {
+        const float t = item_bias[y];
+        item_bias[y] = item_bias_target[y];
+        item_bias_target[y] = t;
+    }
+}
+
+void orc_sgd_pingpong_iterations(const int *indptr, const int *indices, const float *data, int rows, int cols,
+                                 float *P, float *Q, float *Q_target, float *user_bias, float *item_bias,
+                                 float *item_bias_target, float global_bias, const orc_hyper *h, int f, uint64_t seed,
+                                 uint64_t iter0, int n_iters, int dot_order, int update_items, int swap_last) {
+    unsigned char *item_is_updated = (unsigned char *)malloc(cols > 0 ? (size_t)cols : 1); /* training.cu:41-43 */
+    const float lr = h->learning_rate;
+    for (int i = 0; i < n_iters; ++i) {
+        const uint64_t it = iter0 + (uint64_t)i;
+        const int start_user = rows > 0 ? (int)((250u * it) % (uint64_t)rows) : 0; /* training.cu:97-98,115 */
+        memset(item_is_updated, 0, cols > 0 ? (size_t)cols : 1);                   /* training.cu:168 */
+        for (int gid = 0; gid < rows; ++gid) {                                      /* one thread per user, sgd.cu:27 */
+            const int x = (gid + start_user) % rows;
+            const int low = indptr[x], high = indptr[x + 1];
+            if (low == high) continue; /* sgd.cu:34 */
+            const int y_i = orc_sample(seed, (uint64_t)x, it, low, high); /* sgd.cu:36-37 */
+            const int y = indices[y_i];
+            float *p = &P[(size_t)x * f];
+            const float *q = &Q[(size_t)y * f];
+            const float ub = user_bias[x], ib = item_bias[y];
+            const float err = data[y_i] - orc_predict(f, p, q, ub, ib, global_bias, dot_order); /* sgd.cu:45 */
+            const int early_bird = !item_is_updated[y]; /* sgd.cu:49-50 */
+            item_is_updated[y] = 1;
+            for (int k = 0; k < f; ++k) { /* sgd.cu:53-64 */
+                const float p_old = p[k], q_old = q[k];
+                p[k] = p_old + lr * (err * q_old - h->P_reg * p_old);
+                if (update_items && early_bird) Q_target[(size_t)y * f + k] = q_old + lr * (err * p_old - h->Q_reg * q_old);
+            }
+            user_bias[x] = ub + lr * (err - h->user_bias_reg * ub); /* sgd.cu:67 */
+            if (update_items && early_bird) item_bias_target[y] = ib + lr * (err - h->item_bias_reg * ib); /* sgd.cu:71 */
+        }
+        if (i + 1 < n_iters || swap_last) orc_pingpong_swap(Q, Q_target, item_bias, item_bias_target, cols, f);
+    }
+    free(item_is_updated);
+}
+
 int orc_sgd_iterations_parallel(const int *indptr, const int *indices, const float *data, int rows,
                                 float *P, float *Q, float *user_bias, float *item_bias, float global_bias,
                                 const orc_hyper *h, int f, uint64_t seed, uint64_t iter0, int n_iters,

@@ -178,6 +178,32 @@ def sgd_iterations(csr, P, Q, ub, ib, global_bias, hyper, seed, iter0, n_iters, 
                              1 if update_items else 0)
 
 
+def sgd_pingpong_iterations(csr, P, Q, Q_target, ub, ib, ib_target, global_bias, hyper, seed, iter0, n_iters,
+                            dot_order=DOT_SEQ, update_items=True, swap_last=True):
+    """The reference GPU kernel's own semantics (sgd.cu:22-75, training.cu:107-171), in place; see cu2rec_oracle.h."""
+    L = lib()
+    if L.orc_sgd_pingpong_iterations.argtypes is None:
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+        L.orc_sgd_pingpong_iterations.restype = None
+        L.orc_sgd_pingpong_iterations.argtypes = [ip, ip, fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, C.c_float,
+                                                  C.POINTER(Hyper), C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int]
+    for a in (P, Q, Q_target, ub, ib, ib_target):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+    h = Hyper(*[float(v) for v in hyper])
+    L.orc_sgd_pingpong_iterations(_i(csr.indptr), _i(csr.indices), _f(csr.data), csr.rows, csr.cols, _f(P), _f(Q),
+                                  _f(Q_target), _f(ub), _f(ib), _f(ib_target), float(global_bias), C.byref(h), P.shape[1],
+                                  seed, iter0, n_iters, dot_order, 1 if update_items else 0, 1 if swap_last else 0)
+
+
+def pingpong_swap(Q, Q_target, ib, ib_target):
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_pingpong_swap.restype = None
+    L.orc_pingpong_swap.argtypes = [fp, fp, fp, fp, C.c_int, C.c_int]
+    L.orc_pingpong_swap(_f(Q), _f(Q_target), _f(ib), _f(ib_target), Q.shape[0], Q.shape[1])
+
+
 def sgd_one(csr, x, P, Q, ub, ib, global_bias, hyper, seed, it, dot_order=DOT_SEQ, update_items=True):
     """One update of user x at iteration `it`, in place (the loop body, mf_sequential.cu:104-142)."""
     L = lib()
