@@ -49,7 +49,7 @@
 
 #ifndef CU2REC_RES_ABLATE
 #define CU2REC_RES_ABLATE 0  // timing-only builds (tools/build_variant.sh), bits: 1 no grid barrier, 2 no updates, 4 no item-row
-                             // stores; never set in the shipped library
+                             // stores, 64 / 128 barrier without its release / acquire fence; never set in the shipped library
 #endif
 
 #ifndef CU2REC_RES_NT_PAIRS
@@ -139,7 +139,8 @@ __device__ __forceinline__ void barrier_arrive(const ResidentArgs &ra, unsigned 
                                                     __HIP_MEMORY_SCOPE_AGENT);
         const bool leader = old + 1 == phase * static_cast<unsigned>(bs->n_mine);
         if (leader) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines
+            if (!(CU2REC_RES_ABLATE & 64))                          // 64: timing only, no L2 write-back
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the compiler may drop its own wait here)
             __hip_atomic_fetch_add(ra.words + kWTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -158,7 +159,8 @@ __device__ __forceinline__ bool barrier_wait(const ResidentArgs &ra, unsigned ph
         } else {
             ok = spin_until(gen, phase, ra.status);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // invalidate this CU's L1
+        if (!(CU2REC_RES_ABLATE & 128))                         // 128: timing only, no L1 invalidate
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // invalidate this CU's L1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and wait until it has happened
         bs->ok = ok ? 1 : 0;
     }
