@@ -488,6 +488,11 @@ int cu2rec_hogwild_resident_plan(int n_rows, int n_factors, int n_iters, int *bl
     return rc == CU2REC_OK ? yes : rc;
 }
 
+int cu2rec_hogwild_resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group,
+                                     int *lds_rows) {
+    return resident_geometry(n_rows, n_factors, n_cus, blocks, users_per_group, lds_rows) ? 1 : 0;
+}
+
 int cu2rec_schedule_create(const int *indptr, const int *indices, int n_rows, int n_cols, int nnz,
                            cu2rec_schedule **out) {
     return guarded([&] {

@@ -422,11 +422,11 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
 // spilling, plus (the _LDS variants) what the CU's 160 KB of LDS adds.  Capacity on 256 CUs: f <= 64: 385,000 users,
 // f <= 128: 204,000, f <= 192: 114,000, f <= 256: 81,000.
 struct Variant {
-    int j, r;
+    int j, r, rl;  // rl of the r rows per group live in LDS
     const void *kernel;
 };
-#define CU2REC_RES_VARIANT(J, R, D) {J, R, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, 0>)}
-#define CU2REC_RES_VARIANT_LDS(J, R, D, RL) {J, R, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, RL>)}
+#define CU2REC_RES_VARIANT(J, R, D) {J, R, 0, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, 0>)}
+#define CU2REC_RES_VARIANT_LDS(J, R, D, RL) {J, R, RL, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, RL>)}
 const Variant kVariants[] = {
     CU2REC_RES_VARIANT(1, 4, 4),   CU2REC_RES_VARIANT(1, 8, 4),   CU2REC_RES_VARIANT(1, 12, 4),  CU2REC_RES_VARIANT(1, 16, 4),
     CU2REC_RES_VARIANT(1, 20, 4),  CU2REC_RES_VARIANT(1, 24, 4),  CU2REC_RES_VARIANT(1, 28, 4),  CU2REC_RES_VARIANT(1, 32, 4),
@@ -533,6 +533,26 @@ void resident_check_fault() {
              "process or stream using this GPU?); the model state is undefined.  CU2REC_RESIDENT=0 selects the "
              "one-launch-per-iteration kernel");
     }
+}
+
+namespace {
+
+}  // namespace
+
+// Pure arithmetic of the plan (no device needed): which compiled variant holds n_rows users of this width on n_cus
+// CUs, and the grid that goes with it.  false: the rows do not fit registers + LDS.
+bool resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group, int *lds_rows) {
+    if (n_rows < 1 || n_factors < 1 || n_cus < 1) return false;
+    const long long max_groups = static_cast<long long>(n_cus) * kResGroups;
+    const int need = static_cast<int>(std::min<long long>((n_rows + max_groups - 1) / max_groups, 1 << 20));
+    const int v = variant_for(slots_per_lane((n_factors + 3) / 4), need);
+    if (v < 0) return false;
+    const int r = kVariants[v].r;  // >= need: the grid shrinks instead of running empty steps
+    const long long groups = (n_rows + static_cast<long long>(r) - 1) / r;
+    if (blocks) *blocks = static_cast<int>((groups + kResGroups - 1) / kResGroups);
+    if (users_per_group) *users_per_group = r;
+    if (lds_rows) *lds_rows = kVariants[v].rl;
+    return true;
 }
 
 namespace {

@@ -24,6 +24,10 @@ bool resident_launch(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream)
 // *blocks = workgroups (one per CU) and *users_per_group = rows each 16-lane group keeps in registers.
 bool resident_plan(int n_rows, int n_factors, int n_iters, int *blocks, int *users_per_group);
 
+// The arithmetic behind resident_plan, device independent: geometry for n_rows users on n_cus CUs, or false if the rows
+// do not fit registers + LDS (policy and call length are not considered).
+bool resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group, int *lds_rows);
+
 // Throws if an earlier resident launch on the current device gave up at a grid barrier (bounded spin).
 void resident_check_fault();
 

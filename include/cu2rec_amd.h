@@ -226,6 +226,12 @@ int cu2rec_hogwild_resident(int policy);
  * 16-lane group keeps in registers; both may be NULL), 0 if it would stream, < 0 on error. */
 int cu2rec_hogwild_resident_plan(int n_rows, int n_factors, int n_iters, int *blocks, int *users_per_group);
 
+/* The arithmetic behind cu2rec_hogwild_resident_plan, without a device: 1 if the rows of n_rows users of n_factors floats
+ * fit the registers + LDS of n_cus CUs (then *blocks = workgroups, *users_per_group = rows per 16-lane group, of which
+ * *lds_rows live in LDS; all may be NULL), 0 if they do not.  Policy and call length are not considered. */
+int cu2rec_hogwild_resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group,
+                                     int *lds_rows);
+
 /* Workspace of CU2REC_SGD_ORDERED for one device CSR: item popularity ranks, key/value buffers of the
  * per-iteration schedule, sort scratch.  indptr / indices are device pointers (read once at creation). */
 typedef struct cu2rec_schedule cu2rec_schedule;

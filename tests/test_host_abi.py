@@ -187,3 +187,30 @@ def test_threaded_reader_binary_cache_and_fallback(tmp_path):
     L.cu2rec_ratings_free(h)
     L.cu2rec_ratings_free(h2)
     assert L.cu2rec_ratings_load_binary(str(p).encode(), C.byref(h2)) == -2  # a text file is not a cache
+
+
+def test_resident_geometry_arithmetic():
+    """Planning of the resident Hogwild launches, device independent (cu2rec_amd/csrc/resident.hip): which shapes fit
+    the registers + LDS of a 256-CU MI355X and the grid they get."""
+    import ctypes as C
+    L = cu.lib()
+
+    def geometry(rows, f, cus=256):
+        b, r, l = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        ok = L.cu2rec_hogwild_resident_geometry(rows, f, cus, C.byref(b), C.byref(r), C.byref(l))
+        return ok, b.value, r.value, l.value
+
+    assert geometry(138493, 100) == (1, 255, 17, 0)     # ML-20M shape: 17 rows per group, all in registers, 255 workgroups
+    assert geometry(147000, 128) == (1, 256, 18, 0)     # the most the registers hold at two float4 per lane
+    assert geometry(162541, 100) == (1, 254, 20, 4)     # ML-25M shape: 4 of 20 rows in LDS
+    assert geometry(204800, 128) == (1, 256, 25, 9)     # registers + 147 KB of LDS
+    assert geometry(204801, 128)[0] == 0                # one more does not fit: the call streams
+    assert geometry(480189, 128)[0] == 0                # Netflix shape, one GPU
+    assert geometry(60024, 128) == (1, 235, 8, 0)       # ... and one of its eight shards
+    assert geometry(6040, 50) == (1, 48, 4, 0)          # small sets round up to 4 rows per group on a smaller grid
+    assert geometry(385024, 64)[0] == 1 and geometry(385025, 64)[0] == 0
+    assert geometry(20000, 300)[0] == 0                 # five float4 per lane: no resident variant compiled
+    assert geometry(1000, 100, cus=0)[0] == 0
+    for rows, f in ((138493, 100), (162541, 100), (60024, 128), (6040, 50), (60000, 200), (77777, 256)):
+        ok, b, r, l = geometry(rows, f)
+        assert ok and b <= 256 and b * 32 * r >= rows > (b - 1) * 32 * r and 0 <= l < r
