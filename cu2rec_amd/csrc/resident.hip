@@ -252,7 +252,8 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int slot = lane + kGroup * j;
-        sl.off[j] = slot < a.nslots ? slot : lane % a.nslots;
+        // a duplicate copies a slot of the SAME 256-byte chunk of the row, so that instruction j stays on one region
+        sl.off[j] = slot < a.nslots ? slot : kGroup * j + lane % (a.nslots - kGroup * j);
     }
     sl.last_valid = lane + kGroup * (J - 1) < a.nslots;
 
