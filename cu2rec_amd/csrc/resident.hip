@@ -145,6 +145,11 @@ __device__ __forceinline__ void barrier_arrive(const ResidentArgs &ra, unsigned 
             __hip_atomic_fetch_add(ra.words + kWTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         bs->leader = leader ? 1 : 0;
+        // The acquire half, early: invalidate this CU's L1 NOW, so that it overlaps the wait below.  Between here and the
+        // end of barrier_wait no wave of this workgroup loads an item row or item bias (only the read-only sample arrays),
+        // so nothing another CU rewrites can enter the L1 again before the barrier has passed, and the first item-row
+        // loads after it miss the L1 and are served by the L2, which the XCD leaders' releases have made current.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
 }
 
@@ -160,8 +165,7 @@ __device__ __forceinline__ bool barrier_wait(const ResidentArgs &ra, unsigned ph
             ok = spin_until(gen, phase, ra.status);
         }
         if (!(CU2REC_RES_ABLATE & 128))                         // 128: timing only, no L1 invalidate
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // invalidate this CU's L1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and wait until it has happened
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate issued in barrier_arrive has completed
         bs->ok = ok ? 1 : 0;
     }
     __syncthreads();
