@@ -1,13 +1,14 @@
 // Resident Hogwild SGD for gfx950: the reference's per-iteration launches (training.cu:107-113, sgd_update
-// sgd.cu:22-75) folded into ONE persistent launch that keeps every user's factor row in the register file (and, beyond that, the LDS).
+// sgd.cu:22-75) folded into ONE persistent launch that keeps every user's factor row on the CU -- in the register
+// file and, beyond that, in LDS -- for all iterations of the call.
 //
 // Why: in the streaming kernel (kernels.hip, sgd_hogwild_kernel) half of the 16 f + 32 algorithmic bytes per
 // update are the user's own row going to HBM and back between two launches, although nobody else ever
 // touches it.  An MI355X has 256 CUs x 512 KB of vector registers = 128 MB -- more than the whole P matrix
-// of the ML-20M shape (55 MB).  So: one 512-thread workgroup per CU, each 16-lane group owns R = ceil(U / G)
-// users (G = groups in the grid), loads their rows ONCE, runs all iterations of the launch on them and
-// stores them once at the end.  Per iteration only the item side moves: sample -> item id / rating
-// (CSR gather) -> item row read, rank-1 update, item row write.
+// of the ML-20M shape (55 MB).  So: one 512-thread workgroup per CU, each 16-lane group owns R users
+// (R x groups >= users), loads their rows ONCE, runs all iterations of the launch on them and stores them once
+// at the end.  Per iteration only the item side moves: sample -> item id / rating (one gather) -> item row read,
+// rank-1 update, item row write.
 //
 // Semantics are those of one launch per iteration: between two iterations sits a grid-wide barrier with an
 // agent-scope release (every item row written in iteration i has left the XCD's L2) and acquire (the CU's L1
@@ -16,23 +17,25 @@
 // flight, two users that sampled the same item both read the row as it was, the later store wins.
 //
 // Layout inside a group (lanes 0..15 = one DPP row, as everywhere else):
-//   p[r]          Row<J> of the group's r-th user, r < RMAX, in registers for the whole launch
+//   p[r]          Row<J> of the group's r-th user in registers for the whole launch (r < R - RL; the last RL rows
+//                 of a group live in LDS and pass through registers only during their step)
 //   my_*[m]       per-user scalars (row start, row length, user bias, this iteration's sample) are
 //                 LANE-distributed: lane l of set m holds them for user r = 16 m + l, so ONE Philox pass and
 //                 ONE gather per set serve 16 users; a 16-wide shuffle hands them to the group when user r
 //                 is processed.
-// The update loop is software pipelined by hand: the item rows of D users are in flight while one is computed.
-// The arithmetic of an update is the shared device code of sgd_device.hpp, bit for bit.
+// The update loop is straight-line code, software pipelined by hand: the item rows of D users are in flight while
+// one is computed (why it has to be branch free: see sgd_resident_kernel).  The arithmetic of an update is the
+// shared device code of sgd_device.hpp, bit for bit.
 //
 // The grid barrier follows MI355X_MICROARCH.md "Workgroup dispatch, XCD placement & inter-workgroup visibility" and
 // its XCD-hierarchical form ("barrier-xcd"): every wave drains its stores, workgroup barrier, lane 0 arrives on its
 // XCD's counter; the last arriver of an XCD does the ONE agent-scope release for that XCD's L2, reports to the top
 // counter, waits for all XCDs and opens the XCD's generation word, which the other workgroups poll (relaxed sc1
-// loads with s_sleep); everybody ends with an agent acquire fence, drained, workgroup barrier.  (A flat barrier
-// with one release per workgroup cost 28 us per iteration here: 32 L2 write-backs per XCD queue behind each other.)
-// The barrier is split in two halves and the next iteration's sample gathers sit between them.  Every spin is
-// bounded (wall clock): a grid that is not co-resident ends with the status word set instead of hanging, and the
-// host reports it (resident_check_fault).  Residency comes from the grid size alone: at most one workgroup per CU.
+// loads with s_sleep).  (A flat barrier with one release per workgroup cost 28 us per iteration here: 32 L2
+// write-backs per XCD queue behind each other.)  The barrier is split in two halves; the next iteration's sample
+// gathers and the acquire's L1 invalidate sit between them.  Every spin is bounded (wall clock): a grid that is
+// not co-resident ends with the status word set instead of hanging, and the host reports it
+// (resident_check_fault).  Residency comes from the grid size alone: at most one workgroup per CU.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -52,9 +55,6 @@
                              // stores, 64 / 128 barrier without its release / acquire fence; never set in the shipped library
 #endif
 
-#ifndef CU2REC_RES_NT_PAIRS
-#define CU2REC_RES_NT_PAIRS 0  // 1: non-temporal hint on the sample gathers (each line is used once)
-#endif
 #ifndef CU2REC_RES_D2
 #define CU2REC_RES_D2 3  // item rows in flight per group at two float4 per lane (f = 68..128)
 #endif
@@ -81,9 +81,8 @@ constexpr int kBarrierWords = kWGen + kMaxXcc * kLine;
 
 struct ResidentArgs {
     unsigned *words;       // the barrier block above (device memory)
-    unsigned *status;      // set to 1 by a workgroup that gave up waiting (sticky; the host reads it)
+    unsigned *status;      // set to 1 by a workgroup that gave up waiting (the host reads and clears it)
     float *sink;           // kSinkFloats floats nobody reads: where the updates of users without ratings are written
-    int users_per_group;   // R
 };
 constexpr int kSinkBias = 512;                 // sink[0 .. 511]: an item row, sink[512]: an item bias
 constexpr int kSinkFloats = kSinkBias + 16;
@@ -226,15 +225,15 @@ __device__ __forceinline__ float predict_wrapped(const Row<J> &p, const Row<J> &
 // RL of a group's R rows live in the CU's LDS instead of registers (the last RL): 32 groups x RL rows x J x 256 B per
 // workgroup, each lane reading and writing its own 16 bytes (conflict free).  Such a row is read at the start of its
 // step and written back at the end; everything else is the same.  With the 160 KB of LDS a CU holds 9 more rows per
-// group at f <= 128 (26 instead of 17: 213,000 users on 256 CUs).
-template <int J, int RMAX, int D, int RL>
+// group at f <= 128 (16 + 9 = 25: 204,000 users on 256 CUs).
+//
+// J: float4 slots per lane (row width), R: users per group, D: item rows in flight per group, RL: rows kept in LDS.
+template <int J, int R, int D, int RL>
 __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, ResidentArgs ra) {
-    constexpr bool UPD = true;
-    constexpr int R = RMAX;
     constexpr int RREG = R - RL;  // rows in registers
-    static_assert(D >= 1 && D <= RMAX && RL >= 0 && RREG >= 1, "shape");
+    static_assert(D >= 1 && D <= R && RL >= 0 && RREG >= 1, "shape");
     static_assert(sizeof(float4) * kResGroups * RL * J * kGroup + 64 <= 160 * 1024, "LDS rows exceed the CU's 160 KB");
-    constexpr int M = (RMAX + kGroup - 1) / kGroup;  // lane-distributed scalar sets
+    constexpr int M = (R + kGroup - 1) / kGroup;  // lane-distributed scalar sets
     __shared__ BarrierShared s_barrier;
     __shared__ float4 s_rows[RL > 0 ? kResGroups * RL * J * kGroup : 1];
     float4 *my_lds = s_rows + (threadIdx.x / kGroup) * (RL * J * kGroup) + (threadIdx.x & (kGroup - 1));
@@ -299,12 +298,7 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
                 const int y_i = sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + my_x[m]), it, my_low[m],
                                               my_low[m] + my_n[m]);
                 if (a.pairs != nullptr) {  // one 8-byte gather (SgdArgs::pairs)
-#if CU2REC_RES_NT_PAIRS
-                    typedef unsigned uvec2 __attribute__((ext_vector_type(2)));
-                    const uvec2 ir = __builtin_nontemporal_load(reinterpret_cast<const uvec2 *>(a.pairs) + y_i);
-#else
-                    const uint2 ir = a.pairs[y_i];
-#endif
+                    const uint2 ir = a.pairs[y_i];  // (a non-temporal hint here measured +1 us per iteration)
                     item[m] = static_cast<int>(ir.x);
                     rating[m] = __uint_as_float(ir.y);
                 } else {
@@ -318,7 +312,7 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
     int item[M];
     float rating[M];
     draw(a.iter0, item, rating);
-    const bool synced = !(CU2REC_RES_ABLATE & 1) && UPD && a.iters > 1;  // frozen items: nothing crosses users
+    const bool synced = !(CU2REC_RES_ABLATE & 1) && a.iters > 1;
     bool alive = true;
     if (synced) {
         if (threadIdx.x == 0) barrier_census(ra, &s_barrier);
@@ -356,7 +350,7 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
         // to the end of the loop, keeping err * q (4 J registers) alive per user until then: pin it to this step
 #pragma unroll
         for (int j = 0; j < J; ++j) asm volatile("" : "+v"(pc.v[j].x), "+v"(pc.v[j].y), "+v"(pc.v[j].z), "+v"(pc.v[j].w));
-        if (UPD && !(CU2REC_RES_ABLATE & 4)) {                                                              // sgd.cu:61,70
+        if (!(CU2REC_RES_ABLATE & 4)) {                                                              // sgd.cu:61,70
             // the sink is addressed as a byte offset from Q / item_bias so that "real row or sink" is a select
             // between two integers (a select between two pointers comes back as a branch around the stores)
             const int64_t row_off = q_active[s] ? static_cast<int64_t>(q_item[s]) * a.ldq * 4 : sink_row_off;
@@ -609,7 +603,7 @@ bool resident_launch(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream)
     if (s.have_last && s.last_stream != stream) CU2REC_HIP(hipStreamWaitEvent(stream, s.done, 0));  // never two at once
     a.iter0 = iter0;
     a.iters = n_iters;
-    ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink, users_per_group};
+    ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink};
     void *args[] = {&a, &ra};
     CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));  // counters start from zero; status is sticky
     CU2REC_HIP(hipLaunchKernel(kVariants[variant].kernel, dim3(blocks), dim3(kResBlock), args, 0, stream));
