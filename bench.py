@@ -239,9 +239,23 @@ def main():
     log("initial test rmse %.6f" % rmse0)
 
     it = 0
-    job.run(hyper, 42, it, args.warmup, mode)
+    resident_fault = None
+    try:
+        job.run(hyper, 42, it, args.warmup, mode)
+        torch.cuda.synchronize()
+        eng.loss(d_test)  # a resident launch that could not get the GPU to itself reports at the next call: force it here
+    except cu.Cu2recError as e:
+        if "resident" not in str(e) or world > 1:
+            raise
+        # never silently: say so, and measure the one-launch-per-iteration kernel instead of nothing at all
+        resident_fault = str(e)
+        log("RESIDENT LAUNCH FAULT (%s) -- falling back to CU2REC_RESIDENT=0 for this run" % resident_fault)
+        cu.lib().cu2rec_hogwild_resident(0)
+        eng = Engine(train.rows, train.cols, f, train.global_bias, device=device)
+        job = ShardedSGD(eng, d_train, user_offset=user_offset, sync_every=sync_every, merge=args.merge, item_rates=rates)
+        job.run(hyper, 42, it, args.warmup, mode)
+        torch.cuda.synchronize()
     it += args.warmup
-    torch.cuda.synchronize()
     log("warmup done")
     barrier()
     torch.cuda.synchronize()
@@ -385,6 +399,8 @@ def main():
                          "kernel_min_us": 1e3 * kernel_ms_min, "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_update": bytes_per_update, "iterations_per_launch": k_launch},
         }
+        if resident_fault:
+            line["resident_fault"] = resident_fault
         if resident:
             line["roofline"]["note"] = (
                 "one persistent launch = %d iterations; %d workgroups x 32 groups keep %d user rows each in registers, so "
