@@ -107,7 +107,8 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
         const int block = std::max(1, g_hogwild_block.load());
         // the same iterations in ONE persistent launch (grid barrier where the kernel boundary was, user rows
         // resident in registers) whenever the rows fit and the policy allows it: resident.hip
-        if (block == 1 && resident_launch(a, iter0, n_iters, stream)) return;
+        // (n_cols > 0: in a resident launch users without ratings read item row 0 and write to a sink)
+        if (block == 1 && n_cols > 0 && resident_launch(a, iter0, n_iters, stream)) return;
         for (int i = 0; i < n_iters; i += block) {
             a.iter0 = iter0 + static_cast<uint64_t>(i);
             a.iters = std::min(block, n_iters - i);

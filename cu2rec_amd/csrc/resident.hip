@@ -534,22 +534,31 @@ void resident_check_fault() {
     }
 }
 
+// Pure arithmetic of the plan (no device needed): which compiled variant holds n_rows users of this width on n_cus
+// CUs, and the grid that goes with it.  false: the rows do not fit registers + LDS.
 namespace {
+
+// variant index (or -1) and, through `need` / `blocks`, rows per group needed and the grid of the chosen variant
+int geometry(int n_rows, int nslots, int n_cus, int &need, int &blocks) {
+    if (n_rows < 1 || nslots < 1 || n_cus < 1) return -1;
+    const long long max_groups = static_cast<long long>(n_cus) * kResGroups;
+    need = static_cast<int>(std::min<long long>((n_rows + max_groups - 1) / max_groups, 1 << 20));
+    const int v = variant_for(slots_per_lane(nslots), need);
+    if (v < 0) return -1;  // the rows do not fit registers + LDS
+    const int r = kVariants[v].r;  // >= need: the grid shrinks instead of running empty steps
+    const long long groups = (n_rows + static_cast<long long>(r) - 1) / r;
+    blocks = static_cast<int>((groups + kResGroups - 1) / kResGroups);
+    return v;
+}
 
 }  // namespace
 
-// Pure arithmetic of the plan (no device needed): which compiled variant holds n_rows users of this width on n_cus
-// CUs, and the grid that goes with it.  false: the rows do not fit registers + LDS.
 bool resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group, int *lds_rows) {
-    if (n_rows < 1 || n_factors < 1 || n_cus < 1) return false;
-    const long long max_groups = static_cast<long long>(n_cus) * kResGroups;
-    const int need = static_cast<int>(std::min<long long>((n_rows + max_groups - 1) / max_groups, 1 << 20));
-    const int v = variant_for(slots_per_lane((n_factors + 3) / 4), need);
+    int need = 0, b = 0;
+    const int v = n_factors >= 1 ? geometry(n_rows, (n_factors + 3) / 4, n_cus, need, b) : -1;
     if (v < 0) return false;
-    const int r = kVariants[v].r;  // >= need: the grid shrinks instead of running empty steps
-    const long long groups = (n_rows + static_cast<long long>(r) - 1) / r;
-    if (blocks) *blocks = static_cast<int>((groups + kResGroups - 1) / kResGroups);
-    if (users_per_group) *users_per_group = r;
+    if (blocks) *blocks = b;
+    if (users_per_group) *users_per_group = kVariants[v].r;
     if (lds_rows) *lds_rows = kVariants[v].rl;
     return true;
 }
@@ -561,20 +570,15 @@ bool plan_locked(int n_rows, int nslots, int n_iters, int update_items, DeviceSt
                  int &users_per_group) {
     const int policy = resident_policy(-1);
     if (policy == kResidentOff || n_iters < 1 || n_rows < 1 || !update_items) return false;
-    const int j = slots_per_lane(nslots);
     DeviceState &s = state_for_current_device();
     state = &s;
-    if (s.cus < 1) return false;
-    const long long max_groups = static_cast<long long>(s.cus) * kResGroups;
-    const int need = static_cast<int>(std::min<long long>((n_rows + max_groups - 1) / max_groups, 1 << 20));
-    variant = variant_for(j, need);
-    if (variant < 0 || !s.usable[variant]) return false;  // the rows do not fit the register file: stream them
+    int need = 0;
+    variant = geometry(n_rows, nslots, s.cus, need, blocks);
+    if (variant < 0 || !s.usable[variant]) return false;  // the rows do not fit: stream them
     // Auto: the barrier costs a few microseconds where a kernel boundary costs one or two, so residency pays once
     // an iteration moves enough rows per group and the launch is long enough to amortise loading them.
     if (policy == kResidentAuto && (need < 4 || n_iters < 4)) return false;
-    users_per_group = kVariants[variant].r;  // >= need: the grid shrinks instead of running empty steps
-    const long long groups = (n_rows + static_cast<long long>(users_per_group) - 1) / users_per_group;
-    blocks = static_cast<int>((groups + kResGroups - 1) / kResGroups);
+    users_per_group = kVariants[variant].r;
 #ifdef CU2REC_RES_TEST_OVERSUBSCRIBE  // fault-path check only (tools/build_variant.sh): a grid that cannot be co-resident
     blocks *= CU2REC_RES_TEST_OVERSUBSCRIBE;
 #endif
@@ -605,7 +609,7 @@ bool resident_launch(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream)
     a.iters = n_iters;
     ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink};
     void *args[] = {&a, &ra};
-    CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));  // counters start from zero; status is sticky
+    CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));  // counters start from zero
     CU2REC_HIP(hipLaunchKernel(kVariants[variant].kernel, dim3(blocks), dim3(kResBlock), args, 0, stream));
     CU2REC_HIP(hipMemcpyAsync(s.host_status, s.words + kBarrierWords, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     CU2REC_HIP(hipEventRecord(s.done, stream));

@@ -245,3 +245,17 @@ def test_train_loop_with_resident_segments_equals_the_oracle(ml20m_like):
     for e in log:
         assert losses[e["iteration"] - 1] == e["test_rmse"]
     assert cfg.learning_rate == ocfg.learning_rate and cfg.cur_iterations == 12
+
+
+@pytest.mark.parametrize("cols", [1, 0])
+def test_resident_nobody_has_ratings(cols):
+    """Edge: 40,000 users, no rating at all (sgd.cu:34 skips every one of them).  With one item the forced resident
+    launch runs (every user is a sink user); with no item at all the call streams.  Either way nothing changes."""
+    rows, f = 40000, 100
+    m = cu.HostCSR(np.zeros(rows + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), rows, cols, 3.0)
+    model = cu.Model(rows, cols, f, 3.0)
+    before = model.download()
+    with resident_policy(FORCE):
+        model.sgd(cu.DeviceCSR(m), HYPER, 42, 0, 6, mode="hogwild")
+    for b, a in zip(before, model.download()):
+        np.testing.assert_array_equal(a, b)
