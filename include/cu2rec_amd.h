@@ -280,6 +280,8 @@ void cu2rec_csr_destroy(cu2rec_csr *m);
 int cu2rec_model_create(int rows, int cols, int n_factors, const float *P, const float *Q, const float *user_bias,
                         const float *item_bias, float global_bias, cu2rec_model **out);
 int cu2rec_model_info(const cu2rec_model *m, int *rows, int *cols, int *n_factors, int *ld, float *global_bias);
+/* The device arrays of the model (padded rows, stride ld).  Q / item_bias always name the CURRENT item side: after a
+ * CU2REC_SGD_PINGPONG call they may be other buffers than before (the mode swaps two pairs), so ask again. */
 int cu2rec_model_device_ptrs(const cu2rec_model *m, float **P, float **Q, float **user_bias, float **item_bias);
 /* dense host arrays out (any may be NULL): CudaDenseMatrix::to_host + bias copies, training.cu:180-185 */
 int cu2rec_model_download(const cu2rec_model *m, float *P, float *Q, float *user_bias, float *item_bias);
