@@ -104,7 +104,9 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
     } else {
         // one launch per reference iteration (training.cu:107-113): the kernel boundary is the
         // point where every user's update of iteration i is visible to iteration i+1
-        const int block = std::max(1, g_hogwild_block.load());
+        // frozen items (is_train == false, predict.cu:105,126): no update crosses users, so the whole call is ONE launch
+        // with every user's row in registers for all its iterations -- the same results as one launch per iteration
+        const int block = update_items ? std::max(1, g_hogwild_block.load()) : n_iters;
         // the same iterations in ONE persistent launch (grid barrier where the kernel boundary was, user rows
         // resident in registers) whenever the rows fit and the policy allows it: resident.hip
         // (n_cols > 0: in a resident launch users without ratings read item row 0 and write to a sink)
