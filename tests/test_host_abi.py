@@ -214,3 +214,19 @@ def test_resident_geometry_arithmetic():
     for rows, f in ((138493, 100), (162541, 100), (60024, 128), (6040, 50), (60000, 200), (77777, 256)):
         ok, b, r, l = geometry(rows, f)
         assert ok and b <= 256 and b * 32 * r >= rows > (b - 1) * 32 * r and 0 <= l < r
+
+
+def test_integration_shim_compiles(tmp_path):
+    """The reference-side train() shim shown in INTEGRATION.md (Option B) compiles against include/cu2rec_amd.h."""
+    import re
+    import subprocess
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```cpp\n(.*?)```", text, re.S).group(1)
+    stub = ("namespace config { struct Config { int cur_iterations, total_iterations, n_factors, seed, check_error; "
+            "float learning_rate, P_reg, Q_reg, user_bias_reg, item_bias_reg, patience, learning_rate_decay; bool is_train; }; }\n"
+            "#include <cstddef>\n")
+    src = tmp_path / "training_amd.cpp"
+    src.write_text(stub + code)
+    res = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert res.returncode == 0, res.stdout
