@@ -5,7 +5,8 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one reference iteration: one SGD update for every user with at least one rating
-(sgd.cu:27-37).  The library is called with 100 iterations at a time (N > 1: one exchange period);
+(sgd.cu:27-37).  The library is called with 500 iterations at a time, the reference's stretch between two
+loss checks (N > 1: one exchange period);
 such a call is ONE resident launch (user rows in the register file, a grid barrier between
 iterations: cu2rec_amd/csrc/resident.hip) when the rows fit, else one launch per iteration.
 Inputs (CSR, P, Q, biases) are resident in HBM before the timed region.  For N > 1 every rank holds its own
@@ -152,7 +153,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--workload", default="ml-20m", choices=["ml-100k", "ml-1m", "ml-20m", "ml-25m", "netflix"])
     ap.add_argument("--factors", type=int, default=100)
     ap.add_argument("--mode", default="hogwild", choices=["hogwild", "serial", "ordered"])
@@ -214,11 +215,12 @@ def main():
     f = args.factors
     hyper = (0.01, 0.02, 0.02, 0.02, 0.02)  # preprocessing/create_config.py:25-32
     # iterations per cu2rec_sgd_update call: N > 1 -> the exchange period (default one epoch = nnz / users iterations);
-    # N = 1 -> nothing to exchange, 100 per call so that every launch of the run has the same length
+    # N = 1 -> nothing to exchange: 500 per call, the stretch between two loss checks of the reference's loop
+    # (check_error = 500, config.h:41-51, training.cu:118) and what cu2rec_train issues
     if world > 1:
         sync_every = args.sync_every or max(1, int(round(train.nnz / max(int(np.count_nonzero(np.diff(train.indptr))), 1))))
     else:
-        sync_every = args.sync_every or 100
+        sync_every = args.sync_every or 500
     user_offset = rank * train.rows  # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the population
     if args.scaling == "strong" and world > 1:
         from cu2rec_amd.parallel import plan_users
