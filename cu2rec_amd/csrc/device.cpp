@@ -288,7 +288,7 @@ void download_padded(const DeviceBuffer<float> &src, float *host, int rows, int 
 
 DeviceModel::DeviceModel(int rows_, int cols_, int f_, const float *hP, const float *hQ, const float *hub,
                          const float *hib, float gb)
-    : rows(rows_), cols(cols_), n_factors(f_), ld((f_ + 3) & ~3), global_bias(gb) {
+    : rows(rows_), cols(cols_), n_factors(f_), ld((f_ + 3) & ~3), ldq((f_ + 31) & ~31), global_bias(gb) {
     require(rows >= 0 && cols >= 0 && n_factors > 0, "cu2rec_model_create: bad shape");
     if (slots_per_lane(ld / 4) > 8) fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
     require_device();
@@ -301,7 +301,7 @@ DeviceModel::DeviceModel(int rows_, int cols_, int f_, const float *hP, const fl
         return tmp.data();
     };
     upload_padded(P, init_if_null(hP, static_cast<size_t>(rows) * n_factors), rows, n_factors, ld);
-    upload_padded(Q, init_if_null(hQ, static_cast<size_t>(cols) * n_factors), cols, n_factors, ld);
+    upload_padded(Q, init_if_null(hQ, static_cast<size_t>(cols) * n_factors), cols, n_factors, ldq);
     user_bias.allocate(std::max(rows, 1));
     item_bias.allocate(std::max(cols, 1));
     if (rows) user_bias.upload(init_if_null(hub, rows), rows);
@@ -314,7 +314,7 @@ void DeviceModel::download(float *hP, float *hQ, float *hub, float *hib) const {
     CU2REC_HIP(hipDeviceSynchronize());
     resident_check_fault();
     if (hP) download_padded(P, hP, rows, n_factors, ld);
-    if (hQ) download_padded(Q, hQ, cols, n_factors, ld);
+    if (hQ) download_padded(Q, hQ, cols, n_factors, ldq);
     if (hub && rows) user_bias.download(hub, rows);
     if (hib && cols) item_bias.download(hib, cols);
 }
@@ -343,7 +343,7 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
             other_in_sync = true;
         }
         const bool swapped = sgd_update_pingpong(train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr,
-                                                 ld, Q.ptr, Q_other.ptr, ld, user_bias.ptr, item_bias.ptr,
+                                                 ld, Q.ptr, Q_other.ptr, ldq, user_bias.ptr, item_bias.ptr,
                                                  item_bias_other.ptr, claim.ptr, global_bias, n_factors, h, seed, iter0,
                                                  n_iters, update_items, 0, !defer_last_swap, stream);
         if (swapped) {  // Q / item_bias always name the current item side
@@ -358,7 +358,7 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
         if (!train.schedule)
             train.schedule.reset(new OrderedSchedule(train.indptr.ptr, train.indices.ptr, train.rows, cols, train.nnz));
         sgd_update_ordered(*train.schedule, train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr,
-                           ld, Q.ptr, ld, user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters,
+                           ld, Q.ptr, ldq, user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters,
                            update_items, 0, stream);
         return;
     }
@@ -371,7 +371,7 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
         }
         pairs = train.pairs.ptr;
     }
-    sgd_update(train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr, ld, Q.ptr, ld,
+    sgd_update(train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr, ld, Q.ptr, ldq,
                user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters, mode, update_items, 0, stream,
                pairs);
 }
@@ -381,7 +381,7 @@ void DeviceModel::loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq
     // Appendix quirk 6: a test file may have fewer users than train, never more
     require(ratings.rows <= rows && ratings.max_item < cols, "cu2rec_model_loss: ratings exceed the model's shape");
     cu2rec::loss(ratings.indptr.ptr, ratings.indices.ptr, ratings.data.ptr, ratings.rows, ratings.nnz, P.ptr, ld, Q.ptr,
-                 ld, user_bias.ptr, item_bias.ptr, global_bias, n_factors, nullptr, workspace.ptr, sum_abs, sum_sq, mae,
+                 ldq, user_bias.ptr, item_bias.ptr, global_bias, n_factors, nullptr, workspace.ptr, sum_abs, sum_sq, mae,
                  rmse, stream);
 }
 
@@ -573,6 +573,8 @@ int cu2rec_model_create(int rows, int cols, int n_factors, const float *P, const
         *out = new cu2rec_model(rows, cols, n_factors, P, Q, user_bias, item_bias, global_bias);
     });
 }
+
+int cu2rec_model_item_stride(const cu2rec_model *m) { return m ? m->impl.ldq : 0; }
 
 int cu2rec_model_info(const cu2rec_model *m, int *rows, int *cols, int *n_factors, int *ld, float *global_bias) {
     return guarded([&] {

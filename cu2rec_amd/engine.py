@@ -55,7 +55,9 @@ class Engine:
             raise RuntimeError("cu2rec_amd.Engine needs a GPU: the SGD / loss path has no CPU fallback")
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.rows, self.cols, self.f = int(rows), int(cols), int(n_factors)
-        self.ld = (self.f + 3) & ~3
+        self.ld = (self.f + 3) & ~3     # user rows: 16-byte aligned, nothing more (they are streamed or resident)
+        self.ldq = (self.f + 31) & ~31  # item rows: whole 128-byte lines, because several XCDs read AND write them and rows
+        #                                 sharing a line cost coherence misses / partial write-backs
         self.global_bias = float(np.float32(global_bias))
         f = self.f
 
@@ -64,8 +66,8 @@ class Engine:
                 a = api.initialize_normal_array(n, f)
             return np.ascontiguousarray(a, np.float32).reshape(shape)
 
-        self.P = self._padded(init(P, rows * f, (rows, f)))
-        self.Q = self._padded(init(Q, cols * f, (cols, f)))
+        self.P = self._padded(init(P, rows * f, (rows, f)), self.ld)
+        self.Q = self._padded(init(Q, cols * f, (cols, f)), self.ldq)
         self.user_bias = torch.from_numpy(init(user_bias, rows, (rows,))).to(self.device)
         self.item_bias = torch.from_numpy(init(item_bias, cols, (cols,))).to(self.device)
         self.workspace = torch.empty(lib().cu2rec_loss_workspace_bytes() // 8, dtype=torch.float64, device=self.device)
@@ -73,8 +75,8 @@ class Engine:
         self.item_bias_base = None
         self.exchange = None
 
-    def _padded(self, dense):
-        t = torch.zeros((max(dense.shape[0], 1), self.ld), dtype=torch.float32, device=self.device)
+    def _padded(self, dense, ld):
+        t = torch.zeros((max(dense.shape[0], 1), ld), dtype=torch.float32, device=self.device)
         if dense.shape[0]:
             t[:dense.shape[0], :self.f] = torch.from_numpy(dense).to(self.device)
         return t
@@ -85,7 +87,7 @@ class Engine:
         if api._mode(mode) == api.SGD_ORDERED:
             api.sgd_update_ordered(ratings.schedule(), ratings.indptr.data_ptr(), ratings.indices.data_ptr(),
                                    ratings.data.data_ptr(), ratings.rows, self.cols, self.P.data_ptr(), self.ld,
-                                   self.Q.data_ptr(), self.ld, self.user_bias.data_ptr(), self.item_bias.data_ptr(),
+                                   self.Q.data_ptr(), self.ldq, self.user_bias.data_ptr(), self.item_bias.data_ptr(),
                                    self.global_bias, self.f, hyper, seed, iter0, n_iters, update_items, user_offset,
                                    _stream_ptr())
             return
@@ -94,7 +96,7 @@ class Engine:
                 and lib().cu2rec_hogwild_resident_plan(ratings.rows, self.f, n_iters, None, None) == 1):
             pairs = ratings.sample_pairs().data_ptr()  # resident launch: one 8-byte gather per draw
         api.sgd_update(ratings.indptr.data_ptr(), ratings.indices.data_ptr(), ratings.data.data_ptr(), ratings.rows,
-                       self.cols, self.P.data_ptr(), self.ld, self.Q.data_ptr(), self.ld, self.user_bias.data_ptr(),
+                       self.cols, self.P.data_ptr(), self.ld, self.Q.data_ptr(), self.ldq, self.user_bias.data_ptr(),
                        self.item_bias.data_ptr(), self.global_bias, self.f, hyper, seed, iter0, n_iters, mode,
                        update_items, user_offset, _stream_ptr(), pairs)
 
@@ -102,7 +104,7 @@ class Engine:
         assert ratings.rows <= self.rows and ratings.cols <= self.cols
         err = torch.empty(max(ratings.nnz, 1), dtype=torch.float32, device=self.device) if want_errors else None
         out = api.loss_raw(ratings.indptr.data_ptr(), ratings.indices.data_ptr(), ratings.data.data_ptr(),
-                           ratings.rows, ratings.nnz, self.P.data_ptr(), self.ld, self.Q.data_ptr(), self.ld,
+                           ratings.rows, ratings.nnz, self.P.data_ptr(), self.ld, self.Q.data_ptr(), self.ldq,
                            self.user_bias.data_ptr(), self.item_bias.data_ptr(), self.global_bias, self.f,
                            self.workspace.data_ptr(), err.data_ptr() if want_errors else None, _stream_ptr())
         if want_errors:
@@ -130,11 +132,11 @@ class Engine:
         if item_weight is not None:
             check(lib().cu2rec_items_delta_pack_weighted(self.Q.data_ptr(), self.item_bias.data_ptr(),
                                                          self.Q_base.data_ptr(), self.item_bias_base.data_ptr(),
-                                                         item_weight.data_ptr(), self.item_bias.numel(), self.ld,
+                                                         item_weight.data_ptr(), self.item_bias.numel(), self.ldq,
                                                          self.exchange.data_ptr(), _stream_ptr()))
             return self.exchange
         check(lib().cu2rec_items_delta_pack(self.Q.data_ptr(), self.item_bias.data_ptr(), self.Q_base.data_ptr(),
-                                            self.item_bias_base.data_ptr(), self.item_bias.numel(), self.ld,
+                                            self.item_bias_base.data_ptr(), self.item_bias.numel(), self.ldq,
                                             self.exchange.data_ptr(), _stream_ptr()))
         return self.exchange
 
@@ -150,14 +152,14 @@ class Engine:
         from ._lib import check
         check(lib().cu2rec_items_delta_apply_overlapped(self.Q.data_ptr(), self.item_bias.data_ptr(), self.Q_base.data_ptr(),
                                                         self.item_bias_base.data_ptr(), self.Q_snap.data_ptr(),
-                                                        self.item_bias_snap.data_ptr(), self.item_bias.numel(), self.ld,
+                                                        self.item_bias_snap.data_ptr(), self.item_bias.numel(), self.ldq,
                                                         self.exchange.data_ptr(), float(scale), _stream_ptr()))
 
     def apply_item_delta(self, scale=1.0):
         """Q <- Q_base + scale * exchange_Q (same for item_bias); the result is the new snapshot."""
         from ._lib import check
         check(lib().cu2rec_items_delta_apply(self.Q.data_ptr(), self.item_bias.data_ptr(), self.Q_base.data_ptr(),
-                                             self.item_bias_base.data_ptr(), self.item_bias.numel(), self.ld,
+                                             self.item_bias_base.data_ptr(), self.item_bias.numel(), self.ldq,
                                              self.exchange.data_ptr(), float(scale), _stream_ptr()))
 
 

@@ -14,7 +14,9 @@
  * Device data layout ("padded rows"): dense factor matrices are row-major float32 with a row
  * stride `ld` that is a multiple of 4 floats (16 B) and >= n_factors; the padding floats must
  * be zero (they then stay zero under every kernel here).  ld == n_factors is the reference's
- * own layout (matrix.h:21-28) whenever n_factors % 4 == 0.  CSR is exactly the reference's:
+ * own layout (matrix.h:21-28) whenever n_factors % 4 == 0.  Recommended for Q, and what cu2rec_model uses: a stride of
+ * a multiple of 32 floats, i.e. item rows that are whole 128-byte lines -- several XCDs read and write them, and rows
+ * that share a line cost coherence misses and partial-line write-backs.  CSR is exactly the reference's:
  * int32 indptr[rows+1], int32 indices[nnz], float32 data[nnz] (matrix.h:11-19).
  */
 #ifndef CU2REC_AMD_H
@@ -280,7 +282,10 @@ void cu2rec_csr_destroy(cu2rec_csr *m);
 int cu2rec_model_create(int rows, int cols, int n_factors, const float *P, const float *Q, const float *user_bias,
                         const float *item_bias, float global_bias, cu2rec_model **out);
 int cu2rec_model_info(const cu2rec_model *m, int *rows, int *cols, int *n_factors, int *ld, float *global_bias);
-/* The device arrays of the model (padded rows, stride ld).  Q / item_bias always name the CURRENT item side: after a
+/* *ld above is the row stride of P (n_factors rounded up to 4 floats); this is the row stride of Q: n_factors rounded up
+ * to 32 floats, so that every item row is a whole number of 128-byte cache lines (see "Device data layout"). */
+int cu2rec_model_item_stride(const cu2rec_model *m);
+/* The device arrays of the model (padded rows: P with stride ld, Q with cu2rec_model_item_stride).  Q / item_bias always name the CURRENT item side: after a
  * CU2REC_SGD_PINGPONG call they may be other buffers than before (the mode swaps two pairs), so ask again. */
 int cu2rec_model_device_ptrs(const cu2rec_model *m, float **P, float **Q, float **user_bias, float **item_bias);
 /* dense host arrays out (any may be NULL): CudaDenseMatrix::to_host + bias copies, training.cu:180-185 */

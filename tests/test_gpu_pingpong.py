@@ -130,7 +130,7 @@ def test_pingpong_raw_pointer_abi_reports_the_swap():
     swapped = C.c_int(-1)
     h = Hyper(*HYPER)
     check(lib().cu2rec_sgd_update_pingpong(d.indptr.data_ptr(), d.indices.data_ptr(), d.data.data_ptr(), tr.rows, tr.cols,
-                                           eng.P.data_ptr(), eng.ld, eng.Q.data_ptr(), Q_t.data_ptr(), eng.ld,
+                                           eng.P.data_ptr(), eng.ld, eng.Q.data_ptr(), Q_t.data_ptr(), eng.ldq,
                                            eng.user_bias.data_ptr(), eng.item_bias.data_ptr(), ib_t.data_ptr(),
                                            claim.data_ptr(), eng.global_bias, f, C.byref(h), 42, 0, 5, 1, 0, 1,
                                            C.byref(swapped), None))

@@ -207,7 +207,7 @@ def test_resident_through_the_raw_pointer_abi_with_user_offset(with_pairs):
             np.testing.assert_array_equal((packed >> 32).astype(np.uint32).view(np.float32), m.data)
         else:
             api.sgd_update(d.indptr.data_ptr(), d.indices.data_ptr(), d.data.data_ptr(), n, m.cols, eng.P.data_ptr(), eng.ld,
-                           eng.Q.data_ptr(), eng.ld, eng.user_bias.data_ptr(), eng.item_bias.data_ptr(), eng.global_bias, f,
+                           eng.Q.data_ptr(), eng.ldq, eng.user_bias.data_ptr(), eng.item_bias.data_ptr(), eng.global_bias, f,
                            HYPER, 42, 2, 8, cu.SGD_HOGWILD, True, u0, None, None)
     # oracle: the same users placed at their global ids behind u0 empty users
     big = cu.HostCSR(np.concatenate([np.zeros(u0, np.int32), m.indptr]), m.indices, m.data, u0 + n, m.cols, m.global_bias)
