@@ -245,7 +245,10 @@ def main():
     try:
         job.run(hyper, 42, it, args.warmup, mode)
         torch.cuda.synchronize()
-        eng.loss(d_test)  # a resident launch that could not get the GPU to itself reports at the next call: force it here
+        # a resident launch that could not get the GPU to itself reports at the next call into the library: ask now
+        # (not with a loss pass: that would leave the caches in another state for the first timed launch)
+        from cu2rec_amd._lib import check
+        check(cu.lib().cu2rec_check_faults())
     except cu.Cu2recError as e:
         if "resident" not in str(e) or world > 1:
             raise

@@ -481,6 +481,14 @@ int cu2rec_hogwild_iters_per_launch(int k) {
 
 int cu2rec_hogwild_resident(int policy) { return resident_policy(policy); }
 
+int cu2rec_check_faults(void) {
+    return guarded([&] {
+        require_device();
+        CU2REC_HIP(hipDeviceSynchronize());
+        resident_check_fault();
+    });
+}
+
 int cu2rec_hogwild_resident_plan(int n_rows, int n_factors, int n_iters, int *blocks, int *users_per_group) {
     int yes = 0;
     const int rc = guarded([&] {

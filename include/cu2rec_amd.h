@@ -223,6 +223,9 @@ int cu2rec_hogwild_iters_per_launch(int k);
  * barrier gives up after 3 s and the next call into the library returns CU2REC_EHIP (once: the model state is
  * undefined after that, but the library stays usable, e.g. with policy 0). */
 int cu2rec_hogwild_resident(int policy);
+/* Waits for the current device and reports a resident launch that gave up at its barrier (CU2REC_EHIP, once), without
+ * doing any other work: the same check every SGD / loss entry point makes on its way in. */
+int cu2rec_check_faults(void);
 /* 1 if a Hogwild cu2rec_sgd_update call of n_iters iterations on n_rows users would be one resident launch on the
  * current device under the current policy (then *blocks = workgroups, one per CU, and *users_per_group = rows each
  * 16-lane group keeps in registers; both may be NULL), 0 if it would stream, < 0 on error. */
