@@ -12,8 +12,9 @@ import numpy as np
 
 from ._lib import Config, Cu2recError, Hyper, TrainStats, check, lib
 
-SGD_HOGWILD, SGD_SERIAL, SGD_ORDERED, SGD_PINGPONG = 0, 1, 2, 3
-MODES = {"hogwild": SGD_HOGWILD, "serial": SGD_SERIAL, "ordered": SGD_ORDERED, "pingpong": SGD_PINGPONG}
+SGD_HOGWILD, SGD_SERIAL, SGD_ORDERED, SGD_PINGPONG, SGD_BLOCKSOLVE = 0, 1, 2, 3, 4
+MODES = {"hogwild": SGD_HOGWILD, "serial": SGD_SERIAL, "ordered": SGD_ORDERED, "pingpong": SGD_PINGPONG,
+         "blocksolve": SGD_BLOCKSOLVE}
 
 
 def _mode(mode):
@@ -348,6 +349,21 @@ def sgd_update_ordered(schedule, indptr, indices, data, n_rows, n_cols, P, ldp, 
     check(lib().cu2rec_sgd_update_ordered(schedule._h, indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias,
                                           item_bias, float(global_bias), n_factors, C.byref(h), int(seed), int(iter0),
                                           int(n_iters), 1 if update_items else 0, int(user_offset), stream))
+
+
+def sgd_update_blocksolve(schedule, indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias,
+                          global_bias, n_factors, hyper, seed, iter0, n_iters, update_items=True, user_offset=0,
+                          stream=None):
+    """cu2rec_sgd_update_blocksolve on raw device addresses."""
+    h = hyper if isinstance(hyper, Hyper) else Hyper(*[float(x) for x in hyper])
+    check(lib().cu2rec_sgd_update_blocksolve(schedule._h, indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq,
+                                             user_bias, item_bias, float(global_bias), n_factors, C.byref(h), int(seed),
+                                             int(iter0), int(n_iters), 1 if update_items else 0, int(user_offset), stream))
+
+
+def blocksolve_min_rate(rate=0.0):
+    """cu2rec_blocksolve_min_rate: expected updates per iteration from which an item's chain is solved block-wise."""
+    return lib().cu2rec_blocksolve_min_rate(float(rate))
 
 
 def loss_raw(indptr, indices, data, n_rows, nnz, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,

@@ -1,0 +1,70 @@
+// Launch interface of the block-solve SGD mode (CU2REC_SGD_BLOCKSOLVE): sequential semantics
+// (mf_sequential.cu:102-143) with the long item chains solved block-wise; see blocksolve.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace cu2rec {
+
+constexpr int kBsLinks = 32;                        // updates ("links") of a chain per block
+constexpr int kBsTableStride = kBsLinks + 1;        // tables: 1 - a^k, 1 - c^k, a^k, c^k for k = 0..kBsLinks
+constexpr int kBsTableFloats = 4 * kBsTableStride;
+constexpr int kBsMaxSlots = 64;                     // float4 slots per row the solver is compiled for (n_factors <= 256)
+
+struct BsBlockDesc {  // 32 consecutive links of one hot chain
+    int pos0;      // sorted position of the first link
+    int n_valid;   // links in the block (the last block of a chain may be partial); 0 = unused table entry
+    int chain;     // popularity rank of the item
+    int m;         // block number inside the chain
+};
+
+struct BsChainDesc {  // the updates of one iteration that hit one hot item, users ascending
+    int begin, len;  // sorted positions [begin, begin + len)
+    int blk0;        // index of the chain's first block
+    int item;
+};
+
+// One iteration's view of the sorted schedule (ordered.hip) and of the scratch buffers; all device pointers.
+struct BsIteration {
+    const uint32_t *keys;     // [n_active] sorted keys of this iteration
+    const uint64_t *vals;     // [n_active] user << 32 | rating bits
+    int n_active;
+    int n_hot;                // popularity ranks [0, n_hot) are solved block-wise, the others walked link by link
+    uint32_t item_mask;
+    const BsChainDesc *chains;  // [n_hot]
+    const BsBlockDesc *blocks;  // [max_blocks]
+    const int *walk_begin;      // [1] sorted position where the walked chains start
+    const int *item_of_rank;
+    const float *tables;      // [kBsTableFloats]
+    float log2a, log2c;       // log2(1 - lr * Q_reg), log2(1 - lr * item_bias_reg)
+    float *Lbuf;              // [max_blocks][kBsLinks * kBsLinks]  lr * L of each block, [j][k] (column j contiguous in k)
+    float *base;              // [n_active]  r - gb - ub per hot link
+    float *ebuf;              // [n_active]  error of each hot link
+    float *qstart;            // [max_blocks][ldq]  item row at the start of each block
+    int max_blocks;
+    // development aid (cu2rec_debug_blocksolve_stamps): [0] = entries appended so far, then {kernel, id, start, end}
+    // per wavefront in units of the 100 MHz s_memrealtime clock; nullptr in normal operation
+    unsigned long long *stamps;
+    int stamps_cap;
+};
+
+// process-wide stamp buffer for the launches that follow (nullptr = off)
+void bs_set_stamps(unsigned long long *buf, int cap);
+void bs_get_stamps(unsigned long long **buf, int *cap);
+bool bs_supported(int nslots);
+void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream);
+// one workgroup per iteration of the batch: chain and block descriptors
+void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
+                    const int *item_of_rank, int *chain_begin, BsChainDesc *chains, BsBlockDesc *blocks, int *walk_begin,
+                    hipStream_t stream);
+// the three phases of one iteration's hot chains
+void bs_launch_hot(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
+// the other chains of the iteration, walked update by update (independent of the hot chains: other items, other users)
+void bs_launch_walk(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
+
+}  // namespace cu2rec

@@ -164,7 +164,8 @@ void sample_pairs_build(const int *indices, const float *data, int nnz, void *pa
 void sgd_update_ordered(OrderedSchedule &schedule, const int *indptr, const int *indices, const float *data,
                         int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
                         float *item_bias, float global_bias, int n_factors, const cu2rec_hyper &hyper, uint64_t seed,
-                        uint64_t iter0, int n_iters, int update_items, int user_offset, hipStream_t stream) {
+                        uint64_t iter0, int n_iters, int update_items, int user_offset, hipStream_t stream,
+                        bool blocksolve) {
     if (!update_items) {
         // frozen items: no two updates of an iteration share a written row, so the parallel schedule IS the
         // sequential result; no chains needed
@@ -178,7 +179,8 @@ void sgd_update_ordered(OrderedSchedule &schedule, const int *indptr, const int 
                               n_factors, hyper, seed, update_items, user_offset);
     if (n_rows == 0 || n_iters == 0) return;
     require_device();
-    schedule.run(a, iter0, n_iters, stream);
+    resident_check_fault();
+    schedule.run(a, iter0, n_iters, stream, blocksolve);
 }
 
 void loss(const int *indptr, const int *indices, const float *data, int n_rows, int nnz, const float *P, int ldp,
@@ -354,12 +356,12 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
         return;
     }
     other_in_sync = false;  // another mode moves Q on without the second pair
-    if (mode == CU2REC_SGD_ORDERED) {
+    if (mode == CU2REC_SGD_ORDERED || mode == CU2REC_SGD_BLOCKSOLVE) {
         if (!train.schedule)
             train.schedule.reset(new OrderedSchedule(train.indptr.ptr, train.indices.ptr, train.rows, cols, train.nnz));
         sgd_update_ordered(*train.schedule, train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr,
                            ld, Q.ptr, ldq, user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters,
-                           update_items, 0, stream);
+                           update_items, 0, stream, mode == CU2REC_SGD_BLOCKSOLVE);
         return;
     }
     const void *pairs = nullptr;
@@ -525,6 +527,28 @@ int cu2rec_sgd_update_ordered(cu2rec_schedule *schedule, const int *indptr, cons
         sgd_update_ordered(schedule->impl, indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias,
                            global_bias, n_factors, *hyper, seed, iter0, n_iters, update_items, user_offset,
                            as_stream(stream));
+    });
+}
+
+int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, const int *indices, const float *data,
+                                 int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
+                                 float *item_bias, float global_bias, int n_factors, const cu2rec_hyper *hyper,
+                                 uint64_t seed, uint64_t iter0, int n_iters, int update_items, int user_offset,
+                                 void *stream) {
+    return guarded([&] {
+        require(schedule && hyper, "cu2rec_sgd_update_blocksolve: null argument");
+        sgd_update_ordered(schedule->impl, indptr, indices, data, n_rows, n_cols, P, ldp, Q, ldq, user_bias, item_bias,
+                           global_bias, n_factors, *hyper, seed, iter0, n_iters, update_items, user_offset,
+                           as_stream(stream), true);
+    });
+}
+
+float cu2rec_blocksolve_min_rate(float rate) { return blocksolve_min_rate(rate); }
+
+int cu2rec_debug_blocksolve_stamps(void *buffer, int capacity) {
+    return guarded([&] {
+        require(capacity >= 0, "cu2rec_debug_blocksolve_stamps: bad capacity");
+        bs_set_stamps(static_cast<unsigned long long *>(buffer), capacity);
     });
 }
 

@@ -39,7 +39,8 @@ void sample_pairs_build(const int *indices, const float *data, int nnz, void *pa
 void sgd_update_ordered(OrderedSchedule &schedule, const int *indptr, const int *indices, const float *data,
                         int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
                         float *item_bias, float global_bias, int n_factors, const cu2rec_hyper &hyper, uint64_t seed,
-                        uint64_t iter0, int n_iters, int update_items, int user_offset, hipStream_t stream);
+                        uint64_t iter0, int n_iters, int update_items, int user_offset, hipStream_t stream,
+                        bool blocksolve = false);
 
 void loss(const int *indptr, const int *indices, const float *data, int n_rows, int nnz, const float *P, int ldp,
           const float *Q, int ldq, const float *user_bias, const float *item_bias, float global_bias, int n_factors,

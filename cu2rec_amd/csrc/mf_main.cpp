@@ -2,7 +2,7 @@
 // Drop-in for the reference CLI (mf.cu:16-99): same arguments, same stdout lines, same output
 // files; built on the C ABI of libcu2rec_amd.
 //
-//   bin/mf [-c config] [-m hogwild|ordered|serial|pingpong] train.csv test.csv
+//   bin/mf [-c config] [-m hogwild|ordered|blocksolve|serial|pingpong] train.csv test.csv
 #include <getopt.h>
 #include <hip/hip_runtime_api.h>
 
@@ -28,6 +28,7 @@ int main(int argc, char **argv) {
                 mode = std::strcmp(optarg, "serial") == 0    ? CU2REC_SGD_SERIAL
                        : std::strcmp(optarg, "ordered") == 0 ? CU2REC_SGD_ORDERED
                        : std::strcmp(optarg, "pingpong") == 0 ? CU2REC_SGD_PINGPONG
+                       : std::strcmp(optarg, "blocksolve") == 0 ? CU2REC_SGD_BLOCKSOLVE
                                                              : CU2REC_SGD_HOGWILD;
                 break;
             default:
@@ -36,7 +37,7 @@ int main(int argc, char **argv) {
         }
     }
     if (optind + 2 > argc) {
-        std::cerr << "usage: mf [-c config] [-m hogwild|ordered|serial|pingpong] train.csv test.csv\n";
+        std::cerr << "usage: mf [-c config] [-m hogwild|ordered|blocksolve|serial|pingpong] train.csv test.csv\n";
         return -1;
     }
     try {

@@ -29,6 +29,8 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
+#include <cmath>
 #include <cstdlib>
 #include <numeric>
 #include <vector>
@@ -470,13 +472,22 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     if (nnz) CU2REC_HIP(hipMemcpy(indices.data(), d_indices, static_cast<size_t>(nnz) * sizeof(int), hipMemcpyDeviceToHost));
     n_active = 0;
     for (int u = 0; u < n_rows; ++u) n_active += indptr[u + 1] > indptr[u];
-    std::vector<int> count(n_cols, 0), order(n_cols), rank(n_cols);
-    for (int k = 0; k < nnz; ++k) {
-        require(indices[k] >= 0 && indices[k] < n_cols, "ordered schedule: item id out of range");
-        ++count[indices[k]];
+    // popularity = expected updates per iteration: every user draws one of its ratings uniformly (sgd.cu:36-37), so an
+    // item collects sum over its raters of 1 / degree; descending, ties by item id.  Ranks only order the chains
+    // (longest first) and pick the hot ones; results do not depend on them.
+    std::vector<double> rate(n_cols, 0.0);
+    std::vector<int> order(n_cols), rank(n_cols);
+    for (int u = 0; u < n_rows; ++u) {
+        const int low = indptr[u], high = indptr[u + 1];
+        require(low <= high && high <= nnz, "ordered schedule: bad indptr");
+        const double w = high > low ? 1.0 / (high - low) : 0.0;
+        for (int k = low; k < high; ++k) {
+            require(indices[k] >= 0 && indices[k] < n_cols, "ordered schedule: item id out of range");
+            rate[indices[k]] += w;
+        }
     }
     std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int l, int r) { return count[l] > count[r]; });
+    std::stable_sort(order.begin(), order.end(), [&](int l, int r) { return rate[l] > rate[r]; });
     for (int r = 0; r < n_cols; ++r) rank[order[r]] = r;
     item_rank.allocate(n_cols);
     item_rank.upload(rank.data(), n_cols);
@@ -498,10 +509,67 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     temp_bytes = 0;
     CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, dk, dv, static_cast<int>(cap), 0, 32, nullptr));
     temp.allocate(temp_bytes + 16);
+    // block-solve workspace
+    const float min_rate = blocksolve_min_rate(-1.f);
+    n_hot_bs = 0;
+    while (n_hot_bs < n_cols && rate[order[n_hot_bs]] >= min_rate) ++n_hot_bs;
+    n_hot_bs = std::min(n_hot_bs, (1 << item_bits) - 1);
+    max_blocks = n_active / kBsLinks + n_hot_bs + 1;
+    chain_begin.allocate(static_cast<size_t>(max_batch) * (n_hot_bs + 1));
+    walk_begin.allocate(max_batch);
+    bs_chains.allocate(static_cast<size_t>(max_batch) * std::max(n_hot_bs, 1));
+    bs_blocks.allocate(static_cast<size_t>(max_batch) * max_blocks);
+    tables.allocate(kBsTableFloats);
+    if (n_hot_bs > 0) {
+        Lbuf.allocate(static_cast<size_t>(max_blocks) * kBsLinks * kBsLinks);
+        basebuf.allocate(std::max(n_active, 1));
+        ebuf.allocate(std::max(n_active, 1));
+    }
 }
 
-void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream) {
+OrderedSchedule::~OrderedSchedule() {
+    if (side) (void)hipStreamDestroy(side);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+}
+
+namespace {
+std::atomic<float> g_bs_min_rate{-1.f};
+}
+
+float blocksolve_min_rate(float rate) {
+    float prev = g_bs_min_rate.load();
+    if (prev < 0.f) {  // first use: default 8 expected updates per iteration, CU2REC_BLOCKSOLVE_RATE overrides
+        float init = 8.f;
+        if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_RATE")) init = std::max(0.01f, static_cast<float>(std::atof(env)));
+        g_bs_min_rate.compare_exchange_strong(prev, init);
+        prev = g_bs_min_rate.load();
+    }
+    if (rate > 0.f) g_bs_min_rate.store(rate);
+    return prev;
+}
+
+void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream, bool blocksolve) {
     if (n_active == 0) return;
+    if (blocksolve) {
+        if (!bs_supported(a.nslots)) fail(CU2REC_EUNSUPPORTED, "block-solve mode is compiled for n_factors <= 256");
+        const bool same = tables_valid && tables_for.lr == a.h.lr && tables_for.q_reg == a.h.q_reg && tables_for.ib_reg == a.h.ib_reg;
+        if (!same) {  // stream ordered: kernels already queued keep the old tables
+            bs_launch_tables(a.h, tables.ptr, stream);
+            tables_for = a.h;
+            tables_valid = true;
+        }
+        if (n_hot_bs > 0 && qstart_ld != a.ldq) {
+            CU2REC_HIP(hipStreamSynchronize(stream));
+            qstart.allocate(static_cast<size_t>(max_blocks) * a.ldq);
+            qstart_ld = a.ldq;
+        }
+        if (!side) {
+            CU2REC_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            CU2REC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            CU2REC_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+    }
     const uint32_t item_mask = (1u << item_bits) - 1u;
     // ranks [0, n_hot) get a dedicated group each with deep prefetch; keep r + 1 representable in item_bits
     int hot_wanted = kHotChains;
@@ -526,6 +594,44 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         const uint32_t *sk = dk.Current();
         const uint64_t *sv = dv.Current();
         a.iters = 1;
+        if (blocksolve) {
+            bs_launch_plan(sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin.ptr, bs_chains.ptr,
+                           bs_blocks.ptr, walk_begin.ptr, stream);
+            const double la = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.q_reg));
+            const double lc = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.ib_reg));
+            for (int b = 0; b < nb; ++b) {
+                a.iter0 = iter0 + done + b;
+                BsIteration it{};
+                it.keys = sk + static_cast<size_t>(b) * n_active;
+                it.vals = sv + static_cast<size_t>(b) * n_active;
+                it.n_active = n_active;
+                it.n_hot = n_hot_bs;
+                it.item_mask = item_mask;
+                it.chains = bs_chains.ptr + static_cast<size_t>(b) * std::max(n_hot_bs, 1);
+                it.blocks = bs_blocks.ptr + static_cast<size_t>(b) * max_blocks;
+                it.walk_begin = walk_begin.ptr + b;
+                it.item_of_rank = item_of_rank.ptr;
+                it.tables = tables.ptr;
+                it.log2a = static_cast<float>(la);
+                it.log2c = static_cast<float>(lc);
+                it.Lbuf = Lbuf.ptr;
+                it.base = basebuf.ptr;
+                it.ebuf = ebuf.ptr;
+                it.qstart = qstart.ptr;
+                it.max_blocks = max_blocks;
+                bs_get_stamps(&it.stamps, &it.stamps_cap);
+                // the walked chains touch other items and other users than the hot ones: fork, run beside, join
+                CU2REC_HIP(hipEventRecord(ev_fork, stream));
+                CU2REC_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+                bs_launch_walk(a, it, side);
+                CU2REC_HIP(hipEventRecord(ev_join, side));
+                bs_launch_hot(a, it, stream);
+                CU2REC_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+            }
+            CU2REC_HIP(hipGetLastError());
+            done += nb;
+            continue;
+        }
         for (int b = 0; b < nb; ++b) {
             a.iter0 = iter0 + done + b;
             const uint32_t *kb = sk + static_cast<size_t>(b) * n_active;

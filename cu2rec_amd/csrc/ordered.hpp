@@ -7,6 +7,7 @@
 #include <cstdint>
 
 #include "hip_check.hpp"
+#include "blocksolve.hpp"
 #include "kernels.hpp"
 
 namespace cu2rec {
@@ -16,7 +17,9 @@ struct OrderedSchedule {
     // items by popularity and count the users that have ratings).
     OrderedSchedule(const int *d_indptr, const int *d_indices, int n_rows, int n_cols, int nnz);
     // Runs iterations [iter0, iter0 + n_iters) of `a` (pointers, hyper-parameters, seed, user_offset filled in).
-    void run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream);
+    // blocksolve: the chains of the hot items are solved block-wise (blocksolve.hip) instead of walked link by link:
+    // the same sequential semantics up to float rounding, not bit for bit.
+    void run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream, bool blocksolve = false);
 
     int n_rows, n_cols, nnz;
     int n_active = 0;   // users with at least one rating = updates per iteration
@@ -27,6 +30,23 @@ struct OrderedSchedule {
     DeviceBuffer<uint64_t> vals[2];
     DeviceBuffer<unsigned char> temp;
     size_t temp_bytes = 0;
+    // block-solve mode: items are ranked by their expected updates per iteration (sum over raters of 1 / degree);
+    // ranks [0, n_hot_bs) -- at least blocksolve_min_rate() expected updates -- get the block-wise treatment
+    int n_hot_bs = 0;
+    int max_blocks = 0;      // blocks of 32 links per iteration, upper bound
+    int qstart_ld = 0;
+    SgdHyper tables_for{};   // hyper-parameters the decay tables were computed from
+    bool tables_valid = false;
+    DeviceBuffer<int> chain_begin, walk_begin;
+    DeviceBuffer<BsChainDesc> bs_chains;
+    DeviceBuffer<BsBlockDesc> bs_blocks;
+    DeviceBuffer<float> tables, Lbuf, basebuf, ebuf, qstart;
+    hipStream_t side = nullptr;            // the walked chains of an iteration run beside its three phases
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    ~OrderedSchedule();
 };
+
+// minimum expected updates per iteration of an item for block-wise treatment (process-wide; schedules created later)
+float blocksolve_min_rate(float rate);
 
 }  // namespace cu2rec

@@ -84,12 +84,12 @@ class Engine:
     # ---- hot path -------------------------------------------------------------------------
     def sgd(self, ratings, hyper, seed, iter0, n_iters, mode=api.SGD_HOGWILD, update_items=True, user_offset=0):
         assert ratings.rows <= self.rows and ratings.cols <= self.cols
-        if api._mode(mode) == api.SGD_ORDERED:
-            api.sgd_update_ordered(ratings.schedule(), ratings.indptr.data_ptr(), ratings.indices.data_ptr(),
-                                   ratings.data.data_ptr(), ratings.rows, self.cols, self.P.data_ptr(), self.ld,
-                                   self.Q.data_ptr(), self.ldq, self.user_bias.data_ptr(), self.item_bias.data_ptr(),
-                                   self.global_bias, self.f, hyper, seed, iter0, n_iters, update_items, user_offset,
-                                   _stream_ptr())
+        if api._mode(mode) in (api.SGD_ORDERED, api.SGD_BLOCKSOLVE):
+            fn = api.sgd_update_ordered if api._mode(mode) == api.SGD_ORDERED else api.sgd_update_blocksolve
+            fn(ratings.schedule(), ratings.indptr.data_ptr(), ratings.indices.data_ptr(),
+               ratings.data.data_ptr(), ratings.rows, self.cols, self.P.data_ptr(), self.ld,
+               self.Q.data_ptr(), self.ldq, self.user_bias.data_ptr(), self.item_bias.data_ptr(),
+               self.global_bias, self.f, hyper, seed, iter0, n_iters, update_items, user_offset, _stream_ptr())
             return
         pairs = None
         if (api._mode(mode) == api.SGD_HOGWILD and update_items and ratings.nnz and hasattr(ratings, "sample_pairs")

@@ -163,7 +163,15 @@ typedef enum cu2rec_sgd_mode {
      * atomicMin, so the mode is deterministic and race free; the reference's surplus threads (grid = rows / n_threads
      * + 1 blocks, which update a few users twice) are not reproduced.  Object layer only (cu2rec_model_sgd,
      * cu2rec_train, bin/mf -m pingpong) or cu2rec_sgd_update_pingpong below. */
-    CU2REC_SGD_PINGPONG = 3
+    CU2REC_SGD_PINGPONG = 3,
+    /* mf_sequential.cu:102-143's semantics at Hogwild-class speed: the schedule of CU2REC_SGD_ORDERED, but the chain of
+     * a popular item (thousands of dependent updates per iteration) is solved 32 updates at a time -- their errors are
+     * the solution of a unit lower triangular system built from the Gram matrix of the 32 user rows (matrix cores), a
+     * scalar forward substitution replaces 32 dependent row updates (cu2rec_amd/csrc/blocksolve.hip).  Equal to the
+     * sequential result up to float rounding (sums are associated differently), NOT bit for bit: tests pin it at
+     * |test RMSE - oracle| <= 1e-4 after 1,000 iterations of the ML-20M shape.  n_factors <= 256.  Needs a
+     * cu2rec_schedule like CU2REC_SGD_ORDERED. */
+    CU2REC_SGD_BLOCKSOLVE = 4
 } cu2rec_sgd_mode;
 
 /* Replaces sgd_update (sgd.cu:22-75) + the per-iteration launch loop of train()
@@ -249,6 +257,23 @@ int cu2rec_sgd_update_ordered(cu2rec_schedule *schedule, const int *indptr, cons
                               float *item_bias, float global_bias, int n_factors, const cu2rec_hyper *hyper,
                               uint64_t seed, uint64_t iter0, int n_iters, int update_items, int user_offset,
                               void *stream);
+
+/* cu2rec_sgd_update in CU2REC_SGD_BLOCKSOLVE mode on raw device pointers (same arguments as the ordered form). */
+int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, const int *indices, const float *data,
+                                 int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
+                                 float *item_bias, float global_bias, int n_factors, const cu2rec_hyper *hyper,
+                                 uint64_t seed, uint64_t iter0, int n_iters, int update_items, int user_offset,
+                                 void *stream);
+/* Which items CU2REC_SGD_BLOCKSOLVE solves block-wise: those expected to receive at least `rate` updates per
+ * iteration (sum over the item's raters of 1 / the rater's number of ratings); the other chains are walked update by
+ * update.  Process-wide, read when a schedule is created; default 8 (CU2REC_BLOCKSOLVE_RATE in the environment
+ * overrides).  Returns the previous value; rate <= 0 only queries. */
+float cu2rec_blocksolve_min_rate(float rate);
+/* Development aid: while `buffer` (device memory, 8 * (1 + 8 * capacity) bytes, zeroed by the caller) is set, every
+ * wavefront of the block-solve kernels writes {kernel, id, start, end, 4 marks (trace builds)} in ticks of the 100 MHz device clock into record
+ * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 5 walk; records never written stay
+ * zero).  NULL switches it off. */
+int cu2rec_debug_blocksolve_stamps(void *buffer, int capacity);
 
 /* Replaces calculate_loss_gpu + get_error_metrics_gpu (loss.cu:19-49,150-200) in ONE pass:
  * residual e = r - (gb + ub + ib + p.q) per rating, sum |e| and sum e^2 accumulated in
