@@ -2,7 +2,7 @@
 // speed.  Same schedule as the ordered mode (ordered.hip: counter-based sample stream -> per-iteration item chains,
 // users ascending inside a chain), but a long chain is no longer walked one dependent update at a time.
 //
-// A chain is a sequence of affine rank-1 maps on the item's state (q, b).  For a block of B = 32 consecutive links with
+// A chain is a sequence of affine rank-1 maps on the item's state (q, b).  For a block of B = 64 consecutive links with
 // user rows p_k, a = 1 - lr*Q_reg, c = 1 - lr*item_bias_reg (tests/test_blocksolve_algebra.py pins these formulas):
 //     (I + lr L) e = rhs,   L_kj  = c^(k-1-j) + a^(k-1-j) (p_k . p_j)  for j < k           unit lower triangular
 //                           rhs_k = (r_k - gb - ub_k) - c^k b0 - a^k (p_k . q0)
@@ -10,18 +10,24 @@
 //     p_k'  = p_k + lr (e_k q^(k) - P_reg p_k),   q^(k) = a^k q0 + lr sum_{j<k} a^(k-1-j) e_j p_j
 // Inside one iteration every user occurs once, so the user rows -- and with them L -- do not depend on any chain's
 // progress.  Per iteration:
-//   phase 1  bs_gram_kernel    every block of every hot chain in parallel: P_blk P_blk^T on the matrix cores
-//                              (v_mfma_f32_32x32x2_f32: exact f32), scaled into lr*L
-//   phase 2  bs_solve_kernel   one workgroup per hot chain walks its blocks: one mat-vec with the block's rows, a
-//                              32-step scalar forward substitution, one transposed mat-vec -- the only sequential part;
-//                              four more wavefronts of the workgroup stream the blocks' rows and L tiles into LDS, six
-//                              blocks ahead (one CU's load path is what bounds a long chain)
-//   phase 3  bs_update_kernel  every block in parallel: the item row as each link saw it = one 32x32 by 32xf product
-//                              (matrix cores again), then the user rows and user biases
-//   beside   bs_walk_kernel    the short chains, one update at a time as in the ordered mode (other items, other users:
-//                              independent of the three phases, launched on a second stream)
+//   phase 1  bs_gram_kernel    every block of every hot chain in parallel, one wavefront each: the Gram matrix of the
+//                              block's 64 user rows on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32), scaled into
+//                              lr*L, and its inverse factor M = (I + lr L)^-1 (two 32x32 triangular inversions on the
+//                              vector unit, the off-diagonal tile as two more matrix products) -- so that e = M rhs
+//   phase 2  bs_solve_kernel   one workgroup per hot chain walks its blocks with ONE wavefront, lane = link: a mat-vec
+//                              with the block's rows, a mat-vec with M, a transposed mat-vec -- the only sequential
+//                              part, no cross-wavefront exchange in it; four more wavefronts stream the blocks' rows
+//                              and factors global -> registers -> LDS, four blocks ahead (one CU's load path is what
+//                              bounds a long chain)
+//   phase 3  bs_update_kernel  every block in parallel: the item row as each link saw it = a 64x64 (lower triangular) by
+//                              64xf product (matrix cores again), then the user rows and user biases
+//   beside   the other chains  in the ordered mode's own kernel (ordered.hip: two-wave form for chains of a dozen links
+//                              and more, windowed walk for the rest) on a second stream: other items, other users
 // Results equal the sequential ones up to float rounding (not bit for bit: the sums are associated differently).
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
 
 #include "blocksolve.hpp"
 #include "hip_check.hpp"
@@ -35,7 +41,8 @@ using namespace dev;
 
 constexpr int kB = kBsLinks;
 constexpr int kTabAdel = 0, kTabCdel = kBsTableStride, kTabApow = 2 * kBsTableStride, kTabCpow = 3 * kBsTableStride;
-constexpr int kWalkWindow = 2;  // sorted positions per 16-lane group (short chains)
+constexpr int kH = 32;   // tile edge: a block is two halves of 32 links
+constexpr int kMS = 36;  // LDS row stride (floats) of a 32x32 tile: 16-byte aligned rows, odd in float4 units
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -72,7 +79,7 @@ struct WaveStamp {
     __device__ __forceinline__ void mark(const BsIteration &it, int i) {
 #if CU2REC_BS_TRACE
         if (it.stamps) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS / scalar only: stores in flight are not part of a phase
             marks[i] = wall_clock64();
         }
 #endif
@@ -163,128 +170,192 @@ __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict
     for (int g = s_total + tid; g < max_blocks; g += 256) bd[g] = BsBlockDesc{0, 0, 0, 0};
 }
 
-// ---- phase 1: lr * L of every block ---------------------------------------------------------------------------------
-// One wavefront per block.  The 32 user rows are gathered with coalesced 128-byte pieces into the wavefront's own LDS
-// tile (odd row stride: a column read is conflict free), then lane (k = l & 31, h = l >> 5) takes half h of row k:
-// v_mfma_f32_32x32x2_f32 wants A[i = l & 31][kk = l >> 5] and B[kk = l >> 5][j = l & 31], so with B = A^T the SAME
-// register is both operands and the contraction index pairs column c of half 0 with column c of half 1.
-__global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it) {
+// ---- phase 1: the inverse factor of every block --------------------------------------------------------------------
+// One wavefront per block.  The 64 user rows are gathered with coalesced 128-byte pieces into LDS (odd row stride: a
+// column read is conflict free).  Lane (k = l & 31, h = l >> 5) takes half h of rows k and 32 + k;
+// v_mfma_f32_32x32x2_f32 wants A[i = l & 31][kk = l >> 5] and B[kk = l >> 5][j = l & 31], so for the two diagonal tiles
+// (B = A^T) the SAME register is both operands, and the contraction index pairs column c of half 0 with column c of
+// half 1.  With N = lr L in tiles [[N00, 0], [N10, N11]] (strictly lower triangular diagonal tiles):
+//     M = (I + N)^-1 = [[M11, 0], [M21, M22]],  M11 = (I + N00)^-1,  M22 = (I + N11)^-1,  M21 = -M22 N10 M11.
+// The two triangular inversions run side by side in the two lane halves (lane = column, forward substitution with the
+// N entries broadcast from LDS); the two products for M21 are matrix-core work again, the first one's accumulator tile
+// being the second one's B operand as it stands.
+__global__ __launch_bounds__(64) void bs_gram_kernel(SgdArgs a, BsIteration it) {
     extern __shared__ float4 bs_smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + wave;
-    if (g >= it.max_blocks) return;
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x;
     WaveStamp stamp(it);
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) return;
-    stamp.mark(it, 0);
     const int nslots = a.nslots, RS = nslots | 1;
-    float4 *tile = bs_smem + static_cast<size_t>(wave) * kB * RS;
-    const int k = lane & 31, h = lane >> 5;
-    const bool valid = k < bd.n_valid;
-    const uint64_t val = valid ? it.vals[bd.pos0 + k] : 0;
+    float4 *tile = bs_smem;  // [kB][RS]; reused for the N / M tiles once the Gram products are done
+    const bool mine = lane < bd.n_valid;  // lane l: link l
+    const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
     const int x = static_cast<int>(val >> 32);
-    if (h == 0 && valid)  // what the link's error starts from: r - gb - ub (mf_sequential.cu:119-126 without b and p.q)
-        it.base[bd.pos0 + k] = (__uint_as_float(static_cast<uint32_t>(val)) - a.global_bias) - a.user_bias[x];
-    stamp.mark(it, 1);
-    // gather: 8 lanes x 16 bytes per row piece, 8 rows per pass
+    if (mine)  // what the link's error starts from: r - gb - ub (mf_sequential.cu:119-126 without b and p.q)
+        it.base[bd.pos0 + lane] = (__uint_as_float(static_cast<uint32_t>(val)) - a.global_bias) - a.user_bias[x];
+    stamp.mark(it, 0);
+    // gather: 8 lanes x 16 bytes per row piece, 8 rows per pass.  Every load is unconditional at a clamped address and
+    // zeroed afterwards: a predicated load makes the compiler branch around it and wait for each one separately.
     const int rsub = lane >> 3, cs = lane & 7;
     const int nch = (nslots + 7) >> 3;
-    for (int c0 = 0; c0 < nch; c0 += 4) {
+    for (int c0 = 0; c0 < nch; c0 += 2) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = 8 * p + rsub;
-            const int xr = __shfl(x, row);
-            const bool rv = row < bd.n_valid;
-            const float4 *src = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(xr) * a.ldp);
-            // every load unconditional at a clamped address, zeroed afterwards: a predicated load makes the compiler
-            // branch around it and wait for each one separately
-            float4 v[4];
+        for (int p0 = 0; p0 < 8; p0 += 2) {
+            float4 v[2][2];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = src[min(8 * (c0 + c) + cs, nslots - 1)];
+            for (int pp = 0; pp < 2; ++pp) {
+                const int xr = __shfl(x, 8 * (p0 + pp) + rsub);
+                const float4 *src = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(xr) * a.ldp);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int slot = 8 * (c0 + c) + cs;
-                if (slot < nslots) tile[row * RS + slot] = rv ? v[c] : zero4();
+                for (int c = 0; c < 2; ++c) v[pp][c] = src[min(8 * (c0 + c) + cs, nslots - 1)];
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int row = 8 * (p0 + pp) + rsub;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int slot = 8 * (c0 + c) + cs;
+                    if (slot < nslots) tile[row * RS + slot] = row < bd.n_valid ? v[pp][c] : zero4();
+                }
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
-    stamp.mark(it, 2);
-    const int S0 = (nslots + 1) >> 1;  // slots per half
-    f32x16 acc;
+    stamp.mark(it, 1);
+    const int k = lane & 31, h = lane >> 5;
+    const int S0 = (nslots + 1) >> 1;  // slots per lane half
+    f32x16 g00, g11, g10;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int c = 0; c < S0; c += 4) {
-        float4 v[4];
+    for (int i = 0; i < 16; ++i) g00[i] = g11[i] = g10[i] = 0.f;
+    for (int c = 0; c < S0; c += 2) {
+        float4 v0[2], v1[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             const int slot = h * S0 + c + i;
-            const float4 t4 = tile[k * RS + min(slot, nslots - 1)];
-            v[i] = c + i < S0 && slot < nslots ? t4 : zero4();
+            const bool ok = c + i < S0 && slot < nslots;
+            const float4 t0 = tile[k * RS + min(slot, nslots - 1)], t1 = tile[(kH + k) * RS + min(slot, nslots - 1)];
+            v0[i] = ok ? t0 : zero4();
+            v1[i] = ok ? t1 : zero4();
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].x, v[i].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].y, v[i].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].z, v[i].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].w, v[i].w, acc, 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            const float p0[4] = {v0[i].x, v0[i].y, v0[i].z, v0[i].w}, p1[4] = {v1[i].x, v1[i].y, v1[i].z, v1[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                g00 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[e], p0[e], g00, 0, 0, 0);
+                g11 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], p1[e], g11, 0, 0, 0);
+                g10 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], p0[e], g10, 0, 0, 0);  // rows: links 32.., columns: links 0..31
+            }
         }
     }
-#if CU2REC_BS_TRACE
-    asm volatile("" : "+v"(acc));  // the product chain ends before the mark
-#endif
-    stamp.mark(it, 3);
-    // the tile is symmetric: read the lane as the link k and the register's row as j; Lbuf[j][k], k contiguous
-    float *L = it.Lbuf + static_cast<size_t>(g) * (kB * kB);
+    stamp.mark(it, 2);
+    __builtin_amdgcn_wave_barrier();  // the tile is dead from here on: its LDS becomes N00 | N11 | N10 | M11 | M22
+    float *Ns = reinterpret_cast<float *>(bs_smem);
+    float *Ms = Ns + 3 * kH * kMS;
+    const float lr = a.h.lr;
+    auto entry = [&](int d, float gram) { return lr * (exp2f(static_cast<float>(d) * it.log2c) + exp2f(static_cast<float>(d) * it.log2a) * gram); };
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int j = acc_row(reg, h);
-        float v = 0.f;
-        if (j < k && valid) {
-            const float d = static_cast<float>(k - 1 - j);
-            v = a.h.lr * (exp2f(d * it.log2c) + exp2f(d * it.log2a) * acc[reg]);
-        }
-        L[j * kB + k] = v;
+        // the diagonal tiles are symmetric: read the lane as the link k and the register's row as j
+        const bool low = j < k;
+        const float n00 = low && k < bd.n_valid ? entry(k - 1 - j, g00[reg]) : 0.f;
+        const float n11 = low && kH + k < bd.n_valid ? entry(k - 1 - j, g11[reg]) : 0.f;
+        Ns[k * kMS + j] = n00;
+        Ns[(kH + k) * kMS + j] = n11;
+        // the off-diagonal tile: register row r = link 32 + r, lane column = link k
+        const int r = j;
+        Ns[(2 * kH + r) * kMS + k] = kH + r < bd.n_valid ? entry(kH + r - 1 - k, g10[reg]) : 0.f;
     }
+    __builtin_amdgcn_wave_barrier();
+    // M11 (lanes 0-31) and M22 (lanes 32-63): lane = column, m[kk] = M[kk][column]
+    float m[kH];
+    {
+        const float *Nh = Ns + h * kH * kMS;
+#pragma unroll
+        for (int kk = 0; kk < kH; ++kk) {
+            float s = kk == k ? 1.f : 0.f;
+#pragma unroll
+            for (int i4 = 0; i4 < (kk + 3) / 4; ++i4) {
+                const float4 n4 = *reinterpret_cast<const float4 *>(Nh + kk * kMS + 4 * i4);
+                if (4 * i4 + 0 < kk) s = __builtin_fmaf(-n4.x, m[4 * i4 + 0], s);
+                if (4 * i4 + 1 < kk) s = __builtin_fmaf(-n4.y, m[4 * i4 + 1], s);
+                if (4 * i4 + 2 < kk) s = __builtin_fmaf(-n4.z, m[4 * i4 + 2], s);
+                if (4 * i4 + 3 < kk) s = __builtin_fmaf(-n4.w, m[4 * i4 + 3], s);
+            }
+            m[kk] = s;
+        }
+    }
+    float *Mg = it.Mbuf + static_cast<size_t>(g) * kBsFactorFloats;
+#pragma unroll
+    for (int kk = 0; kk < kH; ++kk) {
+        Mg[(h ? 2 : 0) * kH * kH + kk * kH + k] = m[kk];
+        Ms[(h * kH + kk) * kMS + k] = m[kk];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // T = N10 M11, then M21 = -M22 T
+    f32x16 tacc, macc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tacc[i] = macc[i] = 0.f;
+    {
+        const float4 *arow = reinterpret_cast<const float4 *>(Ns + (2 * kH + k) * kMS + 16 * h);  // N10[k][16h + s]
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const float4 a4 = arow[t4];
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                tacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], Ms[(16 * h + 4 * t4 + e) * kMS + k], tacc, 0, 0, 0);
+        }
+        // step s contracts over T's rows acc_row(s, 0) and acc_row(s, 1): exactly what lane half h holds in register s
+        const float *mrow = Ms + (kH + k) * kMS + 4 * h;  // M22[k][8 t + 4 h + e] = M22[k][acc_row(4 t + e, h)]
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(mrow + 8 * t4);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) macc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], tacc[4 * t4 + e], macc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) Mg[kH * kH + acc_row(reg, h) * kH + k] = -macc[reg];
+    stamp.mark(it, 3);
     stamp.done(it, 1, g);
 }
 
 // ---- phase 2: the chains ----------------------------------------------------------------------------------------------
-// Workgroup = one hot chain, 8 wavefronts.
-//   wavefronts 0-3 ("solver"): the f columns of the item row are split over them (CW = 4 * SW columns each): the
-//     mat-vec with the block's rows needs one exchange of 32 partial dots per block (the only __syncthreads()), the
-//     transposed mat-vec needs none.  Every solver wavefront runs the forward substitution itself (same inputs, same
-//     bits) instead of waiting for one that does.  They issue no global loads inside the loop.
-//   wavefronts 4-7 ("loader"): stream each block's 32 user rows, L tile and base errors global -> registers -> LDS ring
-//     of three slots, kDepth blocks in flight in the register file: a chain of n links moves n * (4f + 132) bytes
-//     through ONE CU's load path, and that, not the arithmetic, is what a long chain takes.
-template <int SW>
-struct SolveShape {
-    static constexpr int kCols = 4 * SW;           // columns of the item row per solver wavefront
-    static constexpr int kLoads = (SW + 1) / 2;    // float4 per loader thread and tile: slots tp, tp + 8, ...
-};
-
-constexpr int kRing = 3;   // LDS slots: the block being solved, the one before it (transposed mat-vec), the next one
-constexpr int kDepth = 6;  // blocks a loader keeps in flight
+// Workgroup = one hot chain: one solver wavefront (lane = link) and four loader wavefronts.
+//   solver: per block  d = P_blk q (every lane its own row against the item row, broadcast from LDS),
+//           rhs -> e = M rhs (every lane its row of M against rhs, broadcast from LDS), then the item row's columns
+//           (lane = column) collect sum_k w_k P_blk[k][column].  No global loads in the loop, no exchange with other
+//           wavefronts; one __syncthreads() per block hands over the next LDS slot.
+//   loader: streams each block's 64 user rows, factor tiles and base errors global -> registers -> LDS ring of two slots,
+//           kDepth blocks in flight in the register file: a chain of n links moves n * (4f + 196) bytes through ONE
+//           CU's load path, and that is what a long chain takes.
+constexpr int kRing = 2;   // LDS slots: the block being solved and the next one
+constexpr int kDepth = 4;  // blocks a loader keeps in flight
 
 template <int N>
 struct Stage {  // one loader thread's share of a block
     float4 rows[N];
-    float4 l4;
+    float4 m4[4];
     float base;
     uint64_t next_val;  // the thread's schedule entry of the block this stage loads next (kDepth blocks on)
 };
 
-__host__ __device__ inline int solve_slot_f4(int nslots) { return kB * (nslots | 1) + kB * kB / 4 + kB / 4; }
+// LDS slot: [kB][RS] float4 user rows | three factor tiles, rows of kMS floats (column 32 of the first 64 rows: the base error)
+__host__ __device__ inline int solve_slot_f4(int nslots) { return kB * (nslots | 1) + 3 * kH * kMS / 4; }
 
+// after the ring: the item row (4 * sw + 8 float4, zero beyond the row), rhs, w, the decay tables
 __host__ __device__ inline size_t solve_lds_bytes(int nslots, int sw) {
-    return (static_cast<size_t>(kRing) * solve_slot_f4(nslots) + 4 * sw + 2 * kB + kB + (kBsTableFloats + 3) / 4) * 16;
+    return (static_cast<size_t>(kRing) * solve_slot_f4(nslots) + 4 * sw + 8 + kB / 4 + kB / 4 + (kBsTableFloats + 3) / 4) * 16;
 }
 
-template <int SW>
-__global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it) {
+// Four wavefronts = one per SIMD.
+template <int SW>  // float4 slots per row, rounded up to a multiple of 4: 4 * SW >= nslots
+__global__ __launch_bounds__(256) void bs_solve_kernel(SgdArgs a, BsIteration it) {
     extern __shared__ float4 bs_smem[];
-    constexpr int CW = SolveShape<SW>::kCols, NL = SolveShape<SW>::kLoads;
     WaveStamp stamp(it);
     const BsChainDesc cd = it.chains[blockIdx.x];
     const int begin = cd.begin, len = cd.len;
@@ -298,32 +369,40 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
     float4 *smem = bs_smem;
     const int tid = threadIdx.x;
 
-    if (tid >= 256) {
+    if (tid >= 64) {
         // ------------------------------------------------------------------------------------------ loader
-        const int lt = tid - 256, tr = lt >> 3, tp = lt & 7;
+        constexpr int NLT = (4 * SW + 2) / 3;  // float4 per loader thread and block: slots tp, tp + 3, ...
+        const int lt = tid - 64, tr = lt / 3, tp = lt - 3 * tr;
         auto load_val = [&](int t) -> uint64_t { return it.vals[begin + min(kB * t + tr, len - 1)]; };
         // every load is unconditional (clamped addresses): a branch or a predicated load inside the ring would make the
         // compiler's s_waitcnt pass fall back to vmcnt(0) and serialise the ring
-        auto issue = [&](Stage<NL> &s, int t, uint64_t val) {
+        auto issue = [&](Stage<NLT> &s, int t, uint64_t val) {
             s.next_val = load_val(t + kDepth);
             const float4 *row = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(static_cast<uint32_t>(val >> 32)) * a.ldp);
 #pragma unroll
-            for (int i = 0; i < NL; ++i) s.rows[i] = row[min(tp + 8 * i, nslots - 1)];
-            s.l4 = reinterpret_cast<const float4 *>(it.Lbuf + static_cast<size_t>(g0 + min(t, nblk - 1)) * (kB * kB))[lt];
-            s.base = it.base[begin + min(kB * t + (lt & 31), len - 1)];
+            for (int i = 0; i < NLT; ++i) s.rows[i] = row[min(tp + 3 * i, nslots - 1)];
+            const float4 *mg = reinterpret_cast<const float4 *>(it.Mbuf + static_cast<size_t>(g0 + min(t, nblk - 1)) * kBsFactorFloats);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s.m4[q] = mg[q * 192 + lt];
+            s.base = it.base[begin + min(kB * t + (lt & 63), len - 1)];
         };
-        auto commit = [&](const Stage<NL> &s, int t) {  // block t -> ring slot t % kRing; links beyond the chain: zero rows
+        auto commit = [&](const Stage<NLT> &s, int t) {  // block t -> ring slot t % kRing; links beyond the chain: zero rows
             float4 *sl = smem + (t % kRing) * S4;
             const bool rv = kB * t + tr < len;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int slot = tp + 8 * i;
+            for (int i = 0; i < NLT; ++i) {
+                const int slot = tp + 3 * i;
                 if (slot < nslots) sl[tr * RS + slot] = rv ? s.rows[i] : zero4();
             }
-            sl[kB * RS + lt] = s.l4;
-            if (lt < kB) reinterpret_cast<float *>(sl + kB * RS + kB * kB / 4)[lt] = kB * t + lt < len ? s.base : 0.f;
+            float4 *mt = sl + kB * RS;  // three tiles of 32 rows x 8 float4, rows kMS floats apart
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int item = q * 192 + lt;  // float4 number inside the block's factor
+                mt[(item >> 3) * (kMS / 4) + (item & 7)] = s.m4[q];
+            }
+            if (lt < kB) reinterpret_cast<float *>(mt)[lt * kMS + kH] = kB * t + lt < len ? s.base : 0.f;
         };
-        Stage<NL> st[kDepth];
+        Stage<NLT> st[kDepth];
         if (long_chain) {
             uint64_t v[kDepth];
 #pragma unroll
@@ -337,14 +416,14 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
 #pragma unroll
                 for (int u = 0; u < kDepth; ++u) {
                     const int m = m0 + u;
-                    Stage<NL> &s = st[(u + 1) % kDepth];
-                    if (m == 12) stamp.mark(it, 0);
+                    Stage<NLT> &s = st[(u + 1) % kDepth];
+                    if (m == 8) stamp.mark(it, 0);
                     commit(s, m + 1);
-                    if (m == 12) stamp.mark(it, 1);
+                    if (m == 8) stamp.mark(it, 1);
                     issue(s, m + 1 + kDepth, s.next_val);
                     __syncthreads();
-                    if (m == 12) stamp.mark(it, 2);
-                    if (m == 13) stamp.mark(it, 3);
+                    if (m == 8) stamp.mark(it, 2);
+                    if (m == 9) stamp.mark(it, 3);
                 }
             }
         } else {  // everything the chain needs is requested at once
@@ -359,243 +438,263 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
                 __syncthreads();
             }
         }
-        stamp.done(it, 3, static_cast<int>(blockIdx.x) * 8 + (tid >> 6));
+        stamp.done(it, 3, static_cast<int>(blockIdx.x) * 4 + (tid >> 6));
         return;
     }
 
     // ---------------------------------------------------------------------------------------------- solver
-    const int wave = tid >> 6, lane = tid & 63, k = lane & 31, h = lane >> 5;
-    const int ncols = 4 * nslots;
-    float4 *qrow = smem + kRing * S4;          // [4 * SW]
-    float4 *dpart = qrow + 4 * SW;             // [2][kB]: partial dots of the four solver wavefronts
-    float *wbuf = reinterpret_cast<float *>(dpart + 2 * kB);  // [4][kB]
-    float *tab = wbuf + 4 * kB;                // [kBsTableFloats]
-    float *qrow_f = reinterpret_cast<float *>(qrow);
-    for (int i = tid; i < kBsTableFloats; i += 256) tab[i] = it.tables[i];
+    __builtin_amdgcn_s_setprio(3);  // the chain is the critical path of the iteration; whatever shares the CU is not
+    const int k = tid;  // lane = link
+    constexpr int NPS = (SW + 7) / 8;  // passes of 32 slots over the item row
+    float4 *qrow = smem + kRing * S4;                              // [4 * SW + 8]: the item row, zero beyond it
+    float *rbuf = reinterpret_cast<float *>(qrow + 4 * SW + 8);    // [kB]: rhs
+    float *wbuf = rbuf + kB;                                       // [kB]: w
+    float *tab = wbuf + kB;                                        // [kBsTableFloats]
+    for (int i = k; i < kBsTableFloats; i += 64) tab[i] = it.tables[i];
     const int y = cd.item;
-    // the item row: one column per lane
-    const int col = wave * CW + lane;
-    const bool has_col = lane < CW && col < ncols;
-    float qc = has_col ? a.Q[static_cast<size_t>(y) * a.ldq + col] : 0.f;
-    if (lane < CW) qrow_f[col] = qc;
+    const int sl = k & 31, kp = k >> 5;  // transposed mat-vec: lane (slot sl of the pass, link half kp)
+    float4 q4[NPS];                      // the item row, slot 32 p + sl (both lane halves hold it)
+    const float4 *qsrc = reinterpret_cast<const float4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
+#pragma unroll
+    for (int p = 0; p < NPS; ++p) {
+        const int slot = 32 * p + sl;
+        const float4 v = qsrc[min(slot, nslots - 1)];
+        q4[p] = slot < nslots ? v : zero4();
+        if (kp == 0 && slot < 4 * SW + 8) qrow[slot] = q4[p];
+    }
     float b = a.item_bias[y];
     const float lr = a.h.lr;
+    const int kr = k & 31;
+    const bool upper = k >= kH;
     __syncthreads();
     for (int m = 0; m < n_intervals; ++m) {
-        const bool live = m < nblk;  // workgroup uniform
-        const int n = min(kB, len - kB * m);
-        const float4 *tile = smem + (m % kRing) * S4;
-        const float *tile_f = reinterpret_cast<const float *>(tile);
-        const float *Lt = reinterpret_cast<const float *>(tile + kB * RS);
-        if (m == 12) stamp.mark(it, 0);
-        if (live) {
-            // (A) partial dots of the block's rows with this wavefront's columns of the item row
-            float acc = 0.f;
+        if (m < nblk) {  // workgroup uniform
+            const int n = min(kB, len - kB * m);
+            const float4 *tile = smem + (m % kRing) * S4;
+            const float *Mt = reinterpret_cast<const float *>(tile + kB * RS);
+            // this lane's row of M: links 0-31 [M11 row | 0], links 32-63 [M21 row | M22 row]
+            float4 ma[8], mb[8];
+            {
+                const float4 *ra = reinterpret_cast<const float4 *>(Mt + ((upper ? kH : 0) + kr) * kMS);
+                const float4 *rb = reinterpret_cast<const float4 *>(Mt + (2 * kH + kr) * kMS);
 #pragma unroll
-            for (int i = 0; i < SW; ++i) {
-                const int slot = wave * SW + i;
-                if ((i & 1) == h && slot < nslots) {
-                    const float4 p = tile[k * RS + slot], q = qrow[slot];
-                    acc = __builtin_fmaf(p.x, q.x, acc);
-                    acc = __builtin_fmaf(p.y, q.y, acc);
-                    acc = __builtin_fmaf(p.z, q.z, acc);
-                    acc = __builtin_fmaf(p.w, q.w, acc);
+                for (int t = 0; t < 8; ++t) {
+                    ma[t] = ra[t];
+                    const float4 v = rb[t];
+                    mb[t] = upper ? v : zero4();
                 }
             }
-            acc = half_sum(acc);
-            if (h == 0) reinterpret_cast<float *>(&dpart[(m & 1) * kB + k])[wave] = acc;
+            const float base = Mt[k * kMS + kH];
+            const int back = max(n - 1 - k, 0);
+            const float adel_k = tab[kTabAdel + k], cdel_k = tab[kTabCdel + k];
+            const float apr = tab[kTabApow + back], cpr = tab[kTabCpow + back];
+            const float adel_n = tab[kTabAdel + n], cdel_n = tab[kTabCdel + n];
+            if (m == 8) stamp.mark(it, 0);
+            // (A) every link's row against the item row.  Chunks of eight slots, the next chunk's sixteen LDS reads issued
+            // before this chunk's products (the scheduling barriers keep the compiler from sinking the reads next to
+            // their uses: LDS latency, not issue, is what it would pay), four accumulators; slots beyond the row
+            // multiply the item row's zero padding
+            float d;
+            {
+                constexpr int NC = (4 * SW + 7) / 8;
+                float4 pbuf[2][8], qbuf[2][8];
+                const float4 *prow = tile + k * RS;
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    pbuf[0][i] = prow[min(i, nslots - 1)];
+                    qbuf[0][i] = qrow[i];
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (c + 1 < NC) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            pbuf[(c + 1) & 1][i] = prow[min(8 * (c + 1) + i, nslots - 1)];
+                            qbuf[(c + 1) & 1][i] = qrow[8 * (c + 1) + i];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 8; i += 4) {
+                        const float4 *pp = &pbuf[c & 1][i], *qq = &qbuf[c & 1][i];
+                        d0 = __builtin_fmaf(pp[0].x, qq[0].x, d0);
+                        d1 = __builtin_fmaf(pp[1].x, qq[1].x, d1);
+                        d2 = __builtin_fmaf(pp[2].x, qq[2].x, d2);
+                        d3 = __builtin_fmaf(pp[3].x, qq[3].x, d3);
+                        d0 = __builtin_fmaf(pp[0].y, qq[0].y, d0);
+                        d1 = __builtin_fmaf(pp[1].y, qq[1].y, d1);
+                        d2 = __builtin_fmaf(pp[2].y, qq[2].y, d2);
+                        d3 = __builtin_fmaf(pp[3].y, qq[3].y, d3);
+                        d0 = __builtin_fmaf(pp[0].z, qq[0].z, d0);
+                        d1 = __builtin_fmaf(pp[1].z, qq[1].z, d1);
+                        d2 = __builtin_fmaf(pp[2].z, qq[2].z, d2);
+                        d3 = __builtin_fmaf(pp[3].z, qq[3].z, d3);
+                        d0 = __builtin_fmaf(pp[0].w, qq[0].w, d0);
+                        d1 = __builtin_fmaf(pp[1].w, qq[1].w, d1);
+                        d2 = __builtin_fmaf(pp[2].w, qq[2].w, d2);
+                        d3 = __builtin_fmaf(pp[3].w, qq[3].w, d3);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                d = (d0 + d1) + (d2 + d3);
+            }
+            if (m == 8) stamp.mark(it, 1);
+            // (B) e = M rhs
+            const float rhs = k < n ? (base - (b - cdel_k * b)) - (d - adel_k * d) : 0.f;
+            rbuf[k] = rhs;
+            __builtin_amdgcn_wave_barrier();
+            float e = 0.f;
+            {
+                const float4 *rv = reinterpret_cast<const float4 *>(rbuf);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float4 r0 = rv[t], r1 = rv[8 + t];
+                    e = __builtin_fmaf(ma[t].x, r0.x, e);
+                    e = __builtin_fmaf(ma[t].y, r0.y, e);
+                    e = __builtin_fmaf(ma[t].z, r0.z, e);
+                    e = __builtin_fmaf(ma[t].w, r0.w, e);
+                    e = __builtin_fmaf(mb[t].x, r1.x, e);
+                    e = __builtin_fmaf(mb[t].y, r1.y, e);
+                    e = __builtin_fmaf(mb[t].z, r1.z, e);
+                    e = __builtin_fmaf(mb[t].w, r1.w, e);
+                }
+            }
+            if (m == 8) stamp.mark(it, 2);
+            if (k < n) it.ebuf[begin + kB * m + k] = e;
+            // (C) the state the block leaves behind; its start state goes to phase 3
+            wbuf[k] = k < n ? lr * apr * e : 0.f;
+            const float bs = row_sum16(k < n ? lr * cpr * e : 0.f);
+            b = (b - cdel_n * b) + ((lane_value(bs, 0) + lane_value(bs, 16)) + (lane_value(bs, 32) + lane_value(bs, 48)));
+            __builtin_amdgcn_wave_barrier();
+            float4 *qdst = reinterpret_cast<float4 *>(it.qstart + static_cast<size_t>(g0 + m) * a.ldq);
+#pragma unroll
+            for (int p = 0; p < NPS; ++p) {  // lane (slot, half): sum over the half's 32 links of w_k P[k][slot]
+                const int slot = 32 * p + sl;
+                const bool ok = slot < nslots;
+                if (ok && kp == 0) qdst[slot] = q4[p];
+                const float4 *colp = tile + (kH * kp) * RS + min(slot, nslots - 1);
+                const float4 *wv = reinterpret_cast<const float4 *>(wbuf + kH * kp);
+                float4 tb[2][16], wb[2][4];  // all 32 rows of the half requested before the first product
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tb[gq][i] = colp[(16 * gq + i) * RS];
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) wb[gq][t4] = wv[4 * gq + t4];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float4 u = zero4();
+#pragma unroll
+                for (int gq = 0; gq < 2; ++gq) {
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const float wl[4] = {wb[gq][t4].x, wb[gq][t4].y, wb[gq][t4].z, wb[gq][t4].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float4 p4 = tb[gq][4 * t4 + i];
+                            u.x = __builtin_fmaf(wl[i], p4.x, u.x);
+                            u.y = __builtin_fmaf(wl[i], p4.y, u.y);
+                            u.z = __builtin_fmaf(wl[i], p4.z, u.z);
+                            u.w = __builtin_fmaf(wl[i], p4.w, u.w);
+                        }
+                    }
+                }
+                u = make_float4(half_sum(u.x), half_sum(u.y), half_sum(u.z), half_sum(u.w));
+                const float4 qo = q4[p];
+                q4[p] = ok ? make_float4((qo.x - adel_n * qo.x) + u.x, (qo.y - adel_n * qo.y) + u.y,
+                                         (qo.z - adel_n * qo.z) + u.z, (qo.w - adel_n * qo.w) + u.w)
+                           : zero4();
+                if (kp == 0 && slot < 4 * SW + 8) qrow[slot] = q4[p];
+            }
+            if (m == 8) stamp.mark(it, 3);
         }
         __syncthreads();
-        if (m == 12) stamp.mark(it, 1);
-        if (!live) continue;
-        // (B) right-hand side and forward substitution: after step j lane j holds e_j, lanes k > j have it eliminated
-        float Lr[kB];
-#pragma unroll
-        for (int j = 0; j < kB; ++j) Lr[j] = Lt[j * kB + k];
-        const float base = Lt[kB * kB + k];
-        const float4 dp = dpart[(m & 1) * kB + k];
-        const float d = ((dp.x + dp.y) + dp.z) + dp.w;
-        float rhs = k < n ? (base - (b - tab[kTabCdel + k] * b)) - (d - tab[kTabAdel + k] * d) : 0.f;
-#pragma unroll
-        for (int j = 0; j < kB; ++j) rhs = __builtin_fmaf(-Lr[j], lane_value(rhs, j), rhs);
-        const float e = rhs;
-        if (m == 12) stamp.mark(it, 2);
-        if (wave == 0 && h == 0 && k < n) it.ebuf[begin + kB * m + k] = e;
-        // (C) the state the block leaves behind; its start state goes to phase 3
-        const int back = max(n - 1 - k, 0);
-        const float wk = k < n ? lr * tab[kTabApow + back] * e : 0.f;
-        const float bk = k < n ? lr * tab[kTabCpow + back] * e : 0.f;
-        if (h == 0) wbuf[wave * kB + k] = wk;
-        const float bs = row_sum16(bk);
-        b = (b - tab[kTabCdel + n] * b) + (lane_value(bs, 0) + lane_value(bs, 16));
-        if (has_col) it.qstart[static_cast<size_t>(g0 + m) * a.ldq + col] = qc;
-        __builtin_amdgcn_wave_barrier();
-        float upd = 0.f;
-        if constexpr (CW <= 32) {  // lane (column l & 31, half): 16 links each
-            const int cc = wave * CW + k;
-            const bool ok = k < CW && cc < ncols;
-            const float4 *wv = reinterpret_cast<const float4 *>(wbuf + wave * kB + 16 * h);
-#pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const float4 w4 = wv[t4];
-                const float *rowp = tile_f + static_cast<size_t>((16 * h + 4 * t4) * RS) * 4 + cc;
-                upd = __builtin_fmaf(w4.x, ok ? rowp[0] : 0.f, upd);
-                upd = __builtin_fmaf(w4.y, ok ? rowp[RS * 4] : 0.f, upd);
-                upd = __builtin_fmaf(w4.z, ok ? rowp[RS * 8] : 0.f, upd);
-                upd = __builtin_fmaf(w4.w, ok ? rowp[RS * 12] : 0.f, upd);
-            }
-            upd = half_sum(upd);
-        } else {  // lane = column, all 32 links
-            const float4 *wv = reinterpret_cast<const float4 *>(wbuf + wave * kB);
-#pragma unroll
-            for (int t4 = 0; t4 < 8; ++t4) {
-                const float4 w4 = wv[t4];
-                const float *rowp = tile_f + static_cast<size_t>((4 * t4) * RS) * 4 + col;
-                upd = __builtin_fmaf(w4.x, has_col ? rowp[0] : 0.f, upd);
-                upd = __builtin_fmaf(w4.y, has_col ? rowp[RS * 4] : 0.f, upd);
-                upd = __builtin_fmaf(w4.z, has_col ? rowp[RS * 8] : 0.f, upd);
-                upd = __builtin_fmaf(w4.w, has_col ? rowp[RS * 12] : 0.f, upd);
-            }
-        }
-        if (has_col) qc = (qc - tab[kTabAdel + n] * qc) + upd;
-        if (lane < CW) qrow_f[col] = qc;
-        __builtin_amdgcn_wave_barrier();
-        if (m == 12) stamp.mark(it, 3);
     }
-    if (has_col) a.Q[static_cast<size_t>(y) * a.ldq + col] = qc;
-    if (tid == 0) a.item_bias[y] = b;
-    stamp.done(it, 2, static_cast<int>(blockIdx.x) * 8 + wave);
-}
-
-// row load without predicated loads: out-of-row slots re-read the last slot and are zeroed afterwards
-template <int J>
-__device__ __forceinline__ Row<J> load_row_all(const float *__restrict__ base, size_t row, int ld, int nslots, int lane) {
-    const float4 *p = reinterpret_cast<const float4 *>(base + row * static_cast<size_t>(ld));
-    Row<J> r;
+    if (kp == 0) {
+        float4 *qdst = reinterpret_cast<float4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
-        const int slot = lane + kGroup * j;
-        const float4 v = p[min(slot, nslots - 1)];
-        r.v[j] = slot < nslots ? v : zero4();
+        for (int p = 0; p < NPS; ++p)
+            if (32 * p + sl < nslots) qdst[32 * p + sl] = q4[p];
     }
-    return r;
-}
-
-// ---- beside the phases: the other chains ------------------------------------------------------------------------------
-// A 16-lane group walks every chain that starts in its window of sorted positions, one update at a time (the arithmetic
-// of the ordered mode, sgd_device.hpp), the next link's row in flight while this one computes.
-template <int J>
-__global__ __launch_bounds__(256) void bs_walk_kernel(SgdArgs a, BsIteration it) {
-    const int lane = threadIdx.x & (kGroup - 1);
-    const int group = (blockIdx.x * 256 + threadIdx.x) / kGroup;
-    const WaveStamp stamp(it);
-    const int first = *it.walk_begin, n = it.n_active;
-    const int w0 = first + group * kWalkWindow;
-    for (int t = 0; t < kWalkWindow; ++t) {
-        const int start = w0 + t;
-        if (start >= n) break;
-        const uint32_t key = it.keys[start];
-        if (start > first && it.keys[start - 1] == key) continue;  // the chain began in an earlier window
-        const int y = it.item_of_rank[key & it.item_mask];
-        Row<J> q = load_row_all<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
-        float ib = a.item_bias[y];
-        int s = start;
-        uint64_t val = it.vals[s];
-        uint32_t k1 = s + 1 < n ? it.keys[s + 1] : ~key;
-        uint64_t v1 = s + 1 < n ? it.vals[s + 1] : 0;
-        int x = static_cast<int>(val >> 32);
-        Row<J> p = load_row_all<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
-        float ub = a.user_bias[x];
-        for (;;) {
-            const bool more = k1 == key;
-            int nx = 0;
-            Row<J> np = p;
-            float nub = 0.f;
-            uint32_t k2 = ~key;
-            uint64_t v2 = 0;
-            if (more) {
-                nx = static_cast<int>(v1 >> 32);
-                np = load_row_all<J>(a.P, static_cast<size_t>(nx), a.ldp, a.nslots, lane);
-                nub = a.user_bias[nx];
-                if (s + 2 < n) {
-                    k2 = it.keys[s + 2];
-                    v2 = it.vals[s + 2];
-                }
-            }
-            const float rating = __uint_as_float(static_cast<uint32_t>(val));
-            const float err = rating - predict<J>(p, q, ub, ib, a.global_bias);  // sgd.cu:45
-            rank1_update<J>(p, q, err, a.h);                                      // mf_sequential.cu:129-137
-            ib = ib + a.h.lr * (err - a.h.ib_reg * ib);                           // :141
-            store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
-            if (lane == 0) a.user_bias[x] = ub + a.h.lr * (err - a.h.ub_reg * ub);  // :140
-            if (!more) break;
-            ++s;
-            val = v1;
-            x = nx;
-            p = np;
-            ub = nub;
-            k1 = k2;
-            v1 = v2;
-        }
-        store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
-        if (lane == 0) a.item_bias[y] = ib;
-    }
-    if (w0 < n) stamp.done(it, 5, (blockIdx.x * 256 + threadIdx.x) >> 6);
+    if (k == 0) a.item_bias[y] = b;
+    stamp.done(it, 2, static_cast<int>(blockIdx.x) * 4);
 }
 
 // ---- phase 3: the user side of every hot block ---------------------------------------------------------------------
-// One wavefront per (block, 32 columns).  T[k][j] = lr a^(k-1-j) e_j (j < k) is the A operand, the block's user rows the
-// B operand, the accumulator starts from a^k q0: the result is the item row as link k saw it.
+// One wavefront per (block, 32 columns).  T[k][j] = lr a^(k-1-j) e_j (j < k), 64 x 64 lower triangular in three 32 x 32
+// tiles, is the A operand, the block's user rows the B operand, the accumulators start from a^k q0: the result is the
+// item row as link k saw it.
 __global__ __launch_bounds__(256) void bs_update_kernel(SgdArgs a, BsIteration it, int ntiles) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int unit = blockIdx.x * 4 + wave;
     const int g = unit / ntiles, ct = unit - g * ntiles;
     if (g >= it.max_blocks) return;
-    const WaveStamp stamp(it);
+    WaveStamp stamp(it);
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) return;
     const int c = lane & 31, h = lane >> 5;
-    const bool valid = c < bd.n_valid;
-    const uint64_t val = valid ? it.vals[bd.pos0 + c] : 0;
-    const int x = valid ? static_cast<int>(val >> 32) : -1;  // lane l and l + 32: link l & 31
-    const float e = valid ? it.ebuf[bd.pos0 + c] : 0.f;
+    const bool mine = lane < bd.n_valid;  // lane l: link l
+    const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
+    const int x = mine ? static_cast<int>(val >> 32) : -1;
+    const float e_all = it.ebuf[bd.pos0 + min(lane, bd.n_valid - 1)];
+    const float e = mine ? e_all : 0.f;
     const float lr = a.h.lr;
     const int ncols = 4 * a.nslots;
-    const int col = 32 * ct + c;
+    const int col = 32 * ct + c, colc = min(col, ncols - 1);
     const bool colok = col < ncols;
-    float T[16], Bv[16];
+    // operands of step s: the contraction index is 16 h + s inside a 32-link half
+    float t00[16], t10[16], t11[16], b0[16], b1[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         const int j = 16 * h + s;
-        const float ej = h ? lane_value(e, 16 + s) : lane_value(e, s);
-        const int xj = h ? lane_value(x, 16 + s) : lane_value(x, s);
-        T[s] = j < c ? lr * exp2f(static_cast<float>(c - 1 - j) * it.log2a) * ej : 0.f;  // row k = c of T
-        const float pv = a.P[static_cast<size_t>(max(xj, 0)) * a.ldp + min(col, ncols - 1)];  // unconditional, see bs_gram_kernel
-        Bv[s] = xj >= 0 && colok ? pv : 0.f;
+        const float e0 = h ? lane_value(e, 16 + s) : lane_value(e, s);
+        const float e1 = h ? lane_value(e, 48 + s) : lane_value(e, 32 + s);
+        const int x0 = h ? lane_value(x, 16 + s) : lane_value(x, s);
+        const int x1 = h ? lane_value(x, 48 + s) : lane_value(x, 32 + s);
+        const float near = lr * exp2f(static_cast<float>(max(c - 1 - j, 0)) * it.log2a);  // a^(k-1-j) inside a diagonal tile
+        t00[s] = j < c ? near * e0 : 0.f;                                                  // row k = c
+        t11[s] = j < c ? near * e1 : 0.f;                                                  // row 32 + c, column 32 + j
+        t10[s] = lr * exp2f(static_cast<float>(kH + c - 1 - j) * it.log2a) * e0;          // row 32 + c, column j
+        const float p0 = a.P[static_cast<size_t>(max(x0, 0)) * a.ldp + colc];              // unconditional, see bs_gram_kernel
+        const float p1 = a.P[static_cast<size_t>(max(x1, 0)) * a.ldp + colc];
+        b0[s] = x0 >= 0 && colok ? p0 : 0.f;
+        b1[s] = x1 >= 0 && colok ? p1 : 0.f;
     }
-    const float qs_all = it.qstart[static_cast<size_t>(g) * a.ldq + min(col, ncols - 1)];
+    const float qs_all = it.qstart[static_cast<size_t>(g) * a.ldq + colc];
     const float qs = colok ? qs_all : 0.f;
-    f32x16 acc;
+    f32x16 acc0, acc1;
+    float pold0[16], pold1[16];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) acc[reg] = qs * exp2f(static_cast<float>(acc_row(reg, h)) * it.log2a);
-    float pold[16];
+    for (int reg = 0; reg < 16; ++reg) {
+        const int kk = acc_row(reg, h), kk0 = acc_row(reg, 0);
+        acc0[reg] = qs * exp2f(static_cast<float>(kk) * it.log2a);
+        acc1[reg] = qs * exp2f(static_cast<float>(kH + kk) * it.log2a);
+        const int xa = h ? lane_value(x, kk0 + 4) : lane_value(x, kk0);
+        const int xb = h ? lane_value(x, kH + kk0 + 4) : lane_value(x, kH + kk0);
+        pold0[reg] = a.P[static_cast<size_t>(max(xa, 0)) * a.ldp + colc];
+        pold1[reg] = a.P[static_cast<size_t>(max(xb, 0)) * a.ldp + colc];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(t00[s], b0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(t10[s], b0[s], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(t11[s], b1[s], acc1, 0, 0, 0);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int kk0 = acc_row(reg, 0);
-        const int xr = h ? lane_value(x, kk0 + 4) : lane_value(x, kk0);
-        pold[reg] = a.P[static_cast<size_t>(max(xr, 0)) * a.ldp + min(col, ncols - 1)];
+        const int xa = h ? lane_value(x, kk0 + 4) : lane_value(x, kk0);
+        const int xb = h ? lane_value(x, kH + kk0 + 4) : lane_value(x, kH + kk0);
+        const float ea = h ? lane_value(e, kk0 + 4) : lane_value(e, kk0);
+        const float eb = h ? lane_value(e, kH + kk0 + 4) : lane_value(e, kH + kk0);
+        if (xa >= 0 && colok)  // mf_sequential.cu:133-134
+            a.P[static_cast<size_t>(xa) * a.ldp + col] = pold0[reg] + lr * (ea * acc0[reg] - a.h.p_reg * pold0[reg]);
+        if (xb >= 0 && colok)
+            a.P[static_cast<size_t>(xb) * a.ldp + col] = pold1[reg] + lr * (eb * acc1[reg] - a.h.p_reg * pold1[reg]);
     }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(T[s], Bv[s], acc, 0, 0, 0);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int kk0 = acc_row(reg, 0);
-        const int xr = h ? lane_value(x, kk0 + 4) : lane_value(x, kk0);
-        const float er = h ? lane_value(e, kk0 + 4) : lane_value(e, kk0);
-        if (xr >= 0 && colok)  // mf_sequential.cu:133-134
-            a.P[static_cast<size_t>(xr) * a.ldp + col] = pold[reg] + lr * (er * acc[reg] - a.h.p_reg * pold[reg]);
-    }
-    if (ct == 0 && h == 0 && valid) {
+    if (ct == 0 && mine) {
         const float ub = a.user_bias[x];
         a.user_bias[x] = ub + lr * (e - a.h.ub_reg * ub);  // mf_sequential.cu:140
     }
@@ -611,13 +710,11 @@ void launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(bs_solve_kernel<SW>, dim3(it.n_hot), dim3(512), lds, stream, a, it);
-}
-
-template <int J>
-void launch_walk(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
-    const int groups = (it.n_active + kWalkWindow - 1) / kWalkWindow;  // upper bound: the walk starts at walk_begin >= 0
-    hipLaunchKernelGGL(bs_walk_kernel<J>, dim3((groups + 15) / 16), dim3(256), 0, stream, a, it);
+    hipLaunchKernelGGL(bs_solve_kernel<SW>, dim3(it.n_hot), dim3(256), lds, stream, a, it);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess)
+        fail(CU2REC_EHIP, std::string("bs_solve_kernel launch failed: ") + hipGetErrorString(err) + " (SW " + std::to_string(SW) +
+                              ", chains " + std::to_string(it.n_hot) + ", LDS " + std::to_string(lds) + " bytes)");
 }
 
 }  // namespace
@@ -640,7 +737,7 @@ void bs_get_stamps(unsigned long long **buf, int *cap) {
 bool bs_supported(int nslots) { return nslots >= 1 && nslots <= kBsMaxSlots; }
 
 void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream) {
-    hipLaunchKernelGGL(bs_tables_kernel, dim3(1), dim3(64), 0, stream, h, tables);
+    hipLaunchKernelGGL(bs_tables_kernel, dim3(1), dim3(128), 0, stream, h, tables);
 }
 
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
@@ -650,16 +747,21 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
                        item_of_rank, chain_begin, chains, blocks, walk_begin);
 }
 
-void bs_launch_hot(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
+void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
-    const size_t gram_lds = static_cast<size_t>(4) * kB * (a.nslots | 1) * 16;
+    const size_t gram_lds = std::max(static_cast<size_t>(kB) * (a.nslots | 1) * 16, static_cast<size_t>(5) * kH * kMS * 4);
     static bool attr_set = false;
     if (!attr_set) {
         CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bs_gram_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(bs_gram_kernel, dim3((it.max_blocks + 3) / 4), dim3(256), gram_lds, stream, a, it);
+    hipLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(64), gram_lds, stream, a, it);
+    CU2REC_HIP(hipGetLastError());
+}
+
+void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
+    if (it.n_hot <= 0 || it.max_blocks <= 0) return;
     const int sw = (a.nslots + 3) / 4;
     if (sw <= 1) launch_solve<1>(a, it, stream);
     else if (sw <= 2) launch_solve<2>(a, it, stream);
@@ -669,19 +771,13 @@ void bs_launch_hot(const SgdArgs &a, const BsIteration &it, hipStream_t stream) 
     else if (sw <= 12) launch_solve<12>(a, it, stream);
     else if (sw <= 16) launch_solve<16>(a, it, stream);
     else fail(CU2REC_EUNSUPPORTED, "block-solve mode is compiled for n_factors <= 256");
+}
+
+void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
+    if (it.n_hot <= 0 || it.max_blocks <= 0) return;
     const int ntiles = (4 * a.nslots + 31) / 32;
     const long units = static_cast<long>(it.max_blocks) * ntiles;
     hipLaunchKernelGGL(bs_update_kernel, dim3(static_cast<unsigned>((units + 3) / 4)), dim3(256), 0, stream, a, it, ntiles);
-}
-
-void bs_launch_walk(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
-    switch (slots_per_lane(a.nslots)) {
-        case 1: launch_walk<1>(a, it, stream); break;
-        case 2: launch_walk<2>(a, it, stream); break;
-        case 3: launch_walk<3>(a, it, stream); break;
-        case 4: launch_walk<4>(a, it, stream); break;
-        default: fail(CU2REC_EUNSUPPORTED, "block-solve mode is compiled for n_factors <= 256");
-    }
 }
 
 }  // namespace cu2rec

@@ -11,12 +11,13 @@
 
 namespace cu2rec {
 
-constexpr int kBsLinks = 32;                        // updates ("links") of a chain per block
+constexpr int kBsLinks = 64;                        // updates ("links") of a chain per block
 constexpr int kBsTableStride = kBsLinks + 1;        // tables: 1 - a^k, 1 - c^k, a^k, c^k for k = 0..kBsLinks
 constexpr int kBsTableFloats = 4 * kBsTableStride;
+constexpr int kBsFactorFloats = 3 * 32 * 32;        // inverse factor of a block: tiles M11, M21, M22 (32 x 32 each, row major)
 constexpr int kBsMaxSlots = 64;                     // float4 slots per row the solver is compiled for (n_factors <= 256)
 
-struct BsBlockDesc {  // 32 consecutive links of one hot chain
+struct BsBlockDesc {  // up to 64 consecutive links of one hot chain
     int pos0;      // sorted position of the first link
     int n_valid;   // links in the block (the last block of a chain may be partial); 0 = unused table entry
     int chain;     // popularity rank of the item
@@ -42,7 +43,7 @@ struct BsIteration {
     const int *item_of_rank;
     const float *tables;      // [kBsTableFloats]
     float log2a, log2c;       // log2(1 - lr * Q_reg), log2(1 - lr * item_bias_reg)
-    float *Lbuf;              // [max_blocks][kBsLinks * kBsLinks]  lr * L of each block, [j][k] (column j contiguous in k)
+    float *Mbuf;              // [max_blocks][kBsFactorFloats]  (I + lr L)^-1 of each block
     float *base;              // [n_active]  r - gb - ub per hot link
     float *ebuf;              // [n_active]  error of each hot link
     float *qstart;            // [max_blocks][ldq]  item row at the start of each block
@@ -62,9 +63,11 @@ void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream);
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
                     const int *item_of_rank, int *chain_begin, BsChainDesc *chains, BsBlockDesc *blocks, int *walk_begin,
                     hipStream_t stream);
-// the three phases of one iteration's hot chains
-void bs_launch_hot(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
-// the other chains of the iteration, walked update by update (independent of the hot chains: other items, other users)
-void bs_launch_walk(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
+// the three phases of one iteration's hot chains, in this order on one stream
+void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
+void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
+void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
+
+
 
 }  // namespace cu2rec

@@ -307,7 +307,7 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
 template <int W, int S>
 __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32_t *__restrict__ keys,
                                                   const uint64_t *__restrict__ vals, int n_active, uint32_t key_base,
-                                                  int n_hot, const int *__restrict__ item_of_rank) {
+                                                  int n_hot, const int *__restrict__ item_of_rank, int rank_lo) {
     constexpr int kChains = DuoShape<W, S>::kChains, kTile = DuoShape<W, S>::kTile;
     __shared__ DuoLds<W, S> lds[kChains];
     __shared__ int s_range[kChains][2];
@@ -317,7 +317,7 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     const int group = (threadIdx.x & 63) / W;        // lane group inside the wave
     const bool has_chain = group < kChains;          // blocks of fat rows use only some of the groups
     const int c = has_chain ? group : 0;
-    const int r = blockIdx.x * kChains + c;
+    const int r = rank_lo + blockIdx.x * kChains + c;  // ranks below rank_lo belong to somebody else (block-solve mode)
     if (role_a && has_chain) {
         int begin = 0, end = 0;
         if (r < n_hot) {
@@ -404,11 +404,11 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
                                                              const uint64_t *__restrict__ vals, int n_active,
                                                              const int *__restrict__ item_of_rank,
                                                              uint32_t item_mask, uint32_t key_base, int n_hot,
-                                                             int hot_blocks) {
+                                                             int hot_blocks, int rank_lo) {
     const int lane = threadIdx.x & (kGroup - 1);
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
         // two-wave form for every row width: 32 lanes x 1 slot when 65 <= ld <= 128, else 16 lanes x J slots
-        run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank);
+        run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank, rank_lo);
         return;
     }
     const int group = ((blockIdx.x - hot_blocks) * kBlock + threadIdx.x) / kGroup;
@@ -445,13 +445,29 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
 
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
-                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream) {
+                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo = 0) {
+    // ranks [rank_lo, n_hot): the two-wave form; ranks >= n_hot: the windowed walk; ranks < rank_lo: not touched
     const int chains_per_block = DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains;
-    const int hot_blocks = (n_hot + chains_per_block - 1) / chains_per_block;
+    const int hot_blocks = (std::max(n_hot - rank_lo, 0) + chains_per_block - 1) / chains_per_block;
     const int groups = (n_active + kWindow - 1) / kWindow;
     const int blocks = hot_blocks + (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
     hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,
-                       item_of_rank, item_mask, key_base, n_hot, hot_blocks);
+                       item_of_rank, item_mask, key_base, n_hot, hot_blocks, rank_lo);
+}
+
+void launch_chains(const SgdArgs &a, const uint32_t *kb, const uint64_t *vb, int n_active, const int *item_of_rank,
+                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo) {
+    switch (slots_per_lane(a.nslots)) {
+        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
+        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
+        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
+        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
+        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
+        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
+        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
+        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
+        default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
+    }
 }
 
 int bits_for(int n) {  // bits needed to represent values in [0, n)
@@ -514,6 +530,10 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     n_hot_bs = 0;
     while (n_hot_bs < n_cols && rate[order[n_hot_bs]] >= min_rate) ++n_hot_bs;
     n_hot_bs = std::min(n_hot_bs, (1 << item_bits) - 1);
+    // beside the block solves: chains expected to be at least 12 links long run in the ordered mode's two-wave form
+    n_duo_bs = n_hot_bs;
+    while (n_duo_bs < n_cols && n_duo_bs < 4096 && rate[order[n_duo_bs]] >= 12.0) ++n_duo_bs;
+    n_duo_bs = std::min(n_duo_bs, (1 << item_bits) - 1);
     max_blocks = n_active / kBsLinks + n_hot_bs + 1;
     chain_begin.allocate(static_cast<size_t>(max_batch) * (n_hot_bs + 1));
     walk_begin.allocate(max_batch);
@@ -521,7 +541,7 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     bs_blocks.allocate(static_cast<size_t>(max_batch) * max_blocks);
     tables.allocate(kBsTableFloats);
     if (n_hot_bs > 0) {
-        Lbuf.allocate(static_cast<size_t>(max_blocks) * kBsLinks * kBsLinks);
+        Mbuf.allocate(static_cast<size_t>(max_blocks) * kBsFactorFloats);
         basebuf.allocate(std::max(n_active, 1));
         ebuf.allocate(std::max(n_active, 1));
     }
@@ -539,8 +559,8 @@ std::atomic<float> g_bs_min_rate{-1.f};
 
 float blocksolve_min_rate(float rate) {
     float prev = g_bs_min_rate.load();
-    if (prev < 0.f) {  // first use: default 8 expected updates per iteration, CU2REC_BLOCKSOLVE_RATE overrides
-        float init = 8.f;
+    if (prev < 0.f) {  // first use: default 160 expected updates per iteration, CU2REC_BLOCKSOLVE_RATE overrides
+        float init = 160.f;
         if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_RATE")) init = std::max(0.01f, static_cast<float>(std::atof(env)));
         g_bs_min_rate.compare_exchange_strong(prev, init);
         prev = g_bs_min_rate.load();
@@ -565,7 +585,16 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             qstart_ld = a.ldq;
         }
         if (!side) {
-            CU2REC_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            // The chains solved block-wise are the iteration's critical path; what runs beside them gets the lowest
+            // stream priority.  (A CU-masked side stream was tried: three CUs out of four for the walked chains made
+            // an iteration 100 us longer, 273 against 167 us.)
+            int lo = 0, hi = 0;
+            CU2REC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            if (std::getenv("CU2REC_BS_SIDE_PLAIN")) lo = hi = 0;
+            if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess) {
+                (void)hipGetLastError();
+                CU2REC_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            }
             CU2REC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
             CU2REC_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         }
@@ -614,18 +643,25 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.tables = tables.ptr;
                 it.log2a = static_cast<float>(la);
                 it.log2c = static_cast<float>(lc);
-                it.Lbuf = Lbuf.ptr;
+                it.Mbuf = Mbuf.ptr;
                 it.base = basebuf.ptr;
                 it.ebuf = ebuf.ptr;
                 it.qstart = qstart.ptr;
                 it.max_blocks = max_blocks;
                 bs_get_stamps(&it.stamps, &it.stamps_cap);
-                // the walked chains touch other items and other users than the hot ones: fork, run beside, join
+                // The other chains touch other items and other users than the hot ones: fork, run beside, join.  The fork
+                // sits behind phase 1 and the chains' launch comes first: workgroups of the side kernel that already
+                // fill the CUs would keep the chains' workgroups (80 KB of LDS each) waiting, and those are the
+                // iteration's critical path (measured: the chains started 17 us late with the fork in front of phase 1).
+                bs_launch_gram(a, it, stream);
                 CU2REC_HIP(hipEventRecord(ev_fork, stream));
                 CU2REC_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-                bs_launch_walk(a, it, side);
+                bs_launch_solve(a, it, stream);
+                // ranks [n_hot_bs, n_duo_bs): the ordered mode's two-wave chains; beyond: its windowed walk
+                launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask,
+                              static_cast<uint32_t>(b) << item_bits, std::max(n_duo_bs, n_hot_bs), side, n_hot_bs);
                 CU2REC_HIP(hipEventRecord(ev_join, side));
-                bs_launch_hot(a, it, stream);
+                bs_launch_update(a, it, stream);
                 CU2REC_HIP(hipStreamWaitEvent(stream, ev_join, 0));
             }
             CU2REC_HIP(hipGetLastError());
@@ -637,17 +673,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             const uint32_t *kb = sk + static_cast<size_t>(b) * n_active;
             const uint64_t *vb = sv + static_cast<size_t>(b) * n_active;
             const uint32_t key_base = static_cast<uint32_t>(b) << item_bits;
-            switch (slots_per_lane(a.nslots)) {
-                case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
-                case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
-                case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
-                case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
-                case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
-                case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
-                case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
-                case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream); break;
-                default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
-            }
+            launch_chains(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream, 0);
         }
         CU2REC_HIP(hipGetLastError());
         done += nb;

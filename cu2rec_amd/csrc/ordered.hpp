@@ -33,6 +33,7 @@ struct OrderedSchedule {
     // block-solve mode: items are ranked by their expected updates per iteration (sum over raters of 1 / degree);
     // ranks [0, n_hot_bs) -- at least blocksolve_min_rate() expected updates -- get the block-wise treatment
     int n_hot_bs = 0;
+    int n_duo_bs = 0;        // ranks [n_hot_bs, n_duo_bs): the ordered mode's two-wave chains, beside the block solves
     int max_blocks = 0;      // blocks of 32 links per iteration, upper bound
     int qstart_ld = 0;
     SgdHyper tables_for{};   // hyper-parameters the decay tables were computed from
@@ -40,7 +41,7 @@ struct OrderedSchedule {
     DeviceBuffer<int> chain_begin, walk_begin;
     DeviceBuffer<BsChainDesc> bs_chains;
     DeviceBuffer<BsBlockDesc> bs_blocks;
-    DeviceBuffer<float> tables, Lbuf, basebuf, ebuf, qstart;
+    DeviceBuffer<float> tables, Mbuf, basebuf, ebuf, qstart;
     hipStream_t side = nullptr;            // the walked chains of an iteration run beside its three phases
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~OrderedSchedule();

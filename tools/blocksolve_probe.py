@@ -45,7 +45,8 @@ def main():
                   ((users, items, f, iters, rate) + tuple(diffs)), flush=True)
     if args.skip_big:
         return
-    api.blocksolve_min_rate(args.rate if args.rate > 0 else 8.0)
+    if args.rate > 0:
+        api.blocksolve_min_rate(args.rate)
     tr, te = bench.load_dataset(args.workload, 20240917, 0, lambda: None)
     users = int(np.count_nonzero(np.diff(tr.indptr)))
     f = args.factors
@@ -84,10 +85,10 @@ def main():
                 print("   marks after start (mean us over %d waves):" % len(rr), [round(float(v), 2) for v in mk.mean(axis=0)])
                 if kid in (2, 3):
                     for row in rr[:6]:
-                        print("     chain %d wave %d:" % (row[1] // 8, row[1] % 8), [round(float(v - row[2]) / 100.0, 2) for v in row[4:]], "end", round(float(row[3] - row[2]) / 100.0, 2))
+                        print("     chain %d wave %d:" % (row[1] // 4, row[1] % 4), [round(float(v - row[2]) / 100.0, 2) for v in row[4:]], "end", round(float(row[3] - row[2]) / 100.0, 2))
             if kid == 2:
                 order = np.argsort(-dur)[:8]
-                print("   longest solver waves (chain, start, end):", [(int(r[i, 1]) // 8, round(float(st[i]), 2), round(float(en[i]), 2)) for i in order])
+                print("   longest solver waves (chain, start, end):", [(int(r[i, 1]) // 4, round(float(st[i]), 2), round(float(en[i]), 2)) for i in order])
         return
     res = {}
     for mode in ("blocksolve", "ordered"):
