@@ -516,12 +516,13 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     max_batch = 1 << b_bits;
     while (max_batch > 1 && static_cast<size_t>(max_batch) * n_rows > (size_t(1) << 27)) max_batch >>= 1;
     const size_t cap = static_cast<size_t>(max_batch) * std::max(n_rows, 1);
-    keys[0].allocate(cap);
-    keys[1].allocate(cap);
-    vals[0].allocate(cap);
-    vals[1].allocate(cap);
-    hipcub::DoubleBuffer<uint32_t> dk(keys[0].ptr, keys[1].ptr);
-    hipcub::DoubleBuffer<uint64_t> dv(vals[0].ptr, vals[1].ptr);
+    for (int slot = 0; slot < 2; ++slot)
+        for (int i = 0; i < 2; ++i) {
+            keys[slot][i].allocate(cap);
+            vals[slot][i].allocate(cap);
+        }
+    hipcub::DoubleBuffer<uint32_t> dk(keys[0][0].ptr, keys[0][1].ptr);
+    hipcub::DoubleBuffer<uint64_t> dv(vals[0][0].ptr, vals[0][1].ptr);
     temp_bytes = 0;
     CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, dk, dv, static_cast<int>(cap), 0, 32, nullptr));
     temp.allocate(temp_bytes + 16);
@@ -535,10 +536,17 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     while (n_duo_bs < n_cols && n_duo_bs < 4096 && rate[order[n_duo_bs]] >= 12.0) ++n_duo_bs;
     n_duo_bs = std::min(n_duo_bs, (1 << item_bits) - 1);
     max_blocks = n_active / kBsLinks + n_hot_bs + 1;
-    chain_begin.allocate(static_cast<size_t>(max_batch) * (n_hot_bs + 1));
-    walk_begin.allocate(max_batch);
-    bs_chains.allocate(static_cast<size_t>(max_batch) * std::max(n_hot_bs, 1));
-    bs_blocks.allocate(static_cast<size_t>(max_batch) * max_blocks);
+    for (int slot = 0; slot < 2; ++slot) {
+        chain_begin[slot].allocate(static_cast<size_t>(max_batch) * (n_hot_bs + 1));
+        walk_begin[slot].allocate(max_batch);
+        bs_chains[slot].allocate(static_cast<size_t>(max_batch) * std::max(n_hot_bs, 1));
+        bs_blocks[slot].allocate(static_cast<size_t>(max_batch) * max_blocks);
+    }
+    CU2REC_HIP(hipStreamCreateWithFlags(&sched, hipStreamNonBlocking));
+    for (int slot = 0; slot < 2; ++slot) {
+        CU2REC_HIP(hipEventCreateWithFlags(&ev_ready[slot], hipEventDisableTiming));
+        CU2REC_HIP(hipEventCreateWithFlags(&ev_consumed[slot], hipEventDisableTiming));
+    }
     tables.allocate(kBsTableFloats);
     if (n_hot_bs > 0) {
         Mbuf.allocate(static_cast<size_t>(max_blocks) * kBsFactorFloats);
@@ -548,6 +556,11 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
 }
 
 OrderedSchedule::~OrderedSchedule() {
+    if (sched) (void)hipStreamDestroy(sched);
+    for (int slot = 0; slot < 2; ++slot) {
+        if (ev_ready[slot]) (void)hipEventDestroy(ev_ready[slot]);
+        if (ev_consumed[slot]) (void)hipEventDestroy(ev_consumed[slot]);
+    }
     if (side) (void)hipStreamDestroy(side);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -604,28 +617,51 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
     int hot_wanted = kHotChains;
     if (const char *env = std::getenv("CU2REC_ORDERED_HOT")) hot_wanted = std::max(0, std::atoi(env));  // tuning aid
     const int n_hot = std::min(std::min(n_cols, hot_wanted), static_cast<int>(item_mask));
-    int done = 0;
-    while (done < n_iters) {
-        const int nb = std::min(max_batch, n_iters - done);
+    // Sample + sort (+ plan) of one batch into a slot, on the schedule stream: nothing in it depends on the model.
+    struct Scheduled {
+        const uint32_t *sk;
+        const uint64_t *sv;
+    } ready[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    const int n_batches = (n_iters + max_batch - 1) / max_batch;
+    auto schedule = [&](int j) {
+        const int slot = j & 1, first = j * max_batch;
+        const int nb = std::min(max_batch, n_iters - first);
         const int b_bits = bits_for(nb);
         const uint32_t sentinel = 1u << (item_bits + b_bits);
         const size_t n = static_cast<size_t>(nb) * n_rows;
         const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 1 << 16));
-        hipLaunchKernelGGL(schedule_keys_kernel, dim3(blocks), dim3(kBlock), 0, stream, a.indptr, a.indices, a.data,
-                           item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, iter0 + done, a.user_offset,
-                           keys[0].ptr, vals[0].ptr);
+        if (slot_used[slot]) CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[slot], 0));  // its last batch has been run
+        hipLaunchKernelGGL(schedule_keys_kernel, dim3(blocks), dim3(kBlock), 0, sched, a.indptr, a.indices, a.data,
+                           item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, iter0 + first, a.user_offset,
+                           keys[slot][0].ptr, vals[slot][0].ptr);
         CU2REC_HIP(hipGetLastError());
-        hipcub::DoubleBuffer<uint32_t> dk(keys[0].ptr, keys[1].ptr);
-        hipcub::DoubleBuffer<uint64_t> dv(vals[0].ptr, vals[1].ptr);
+        hipcub::DoubleBuffer<uint32_t> dk(keys[slot][0].ptr, keys[slot][1].ptr);
+        hipcub::DoubleBuffer<uint64_t> dv(vals[slot][0].ptr, vals[slot][1].ptr);
         size_t bytes = temp_bytes;
         CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(temp.ptr, bytes, dk, dv, static_cast<int>(n), 0,
-                                                      item_bits + b_bits + 1, stream));
-        const uint32_t *sk = dk.Current();
-        const uint64_t *sv = dv.Current();
+                                                      item_bits + b_bits + 1, sched));
+        ready[slot] = Scheduled{dk.Current(), dv.Current()};
+        if (blocksolve)
+            bs_launch_plan(ready[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
+                           bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched);
+        CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
+        slot_used[slot] = true;
+    };
+    // the CSR / model pointers the schedule reads must be final: whatever the caller queued on `stream` so far
+    CU2REC_HIP(hipEventRecord(ev_consumed[1], stream));
+    CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[1], 0));
+    slot_used[1] = true;  // (that record also stands for "slot 1 free": nothing of it is queued behind this point)
+    schedule(0);
+    int done = 0;
+    for (int j = 0; j < n_batches; ++j) {
+        const int slot = j & 1;
+        const int nb = std::min(max_batch, n_iters - done);
+        if (j + 1 < n_batches) schedule(j + 1);  // runs beside this batch's iterations
+        CU2REC_HIP(hipStreamWaitEvent(stream, ev_ready[slot], 0));
+        const uint32_t *sk = ready[slot].sk;
+        const uint64_t *sv = ready[slot].sv;
         a.iters = 1;
         if (blocksolve) {
-            bs_launch_plan(sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin.ptr, bs_chains.ptr,
-                           bs_blocks.ptr, walk_begin.ptr, stream);
             const double la = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.q_reg));
             const double lc = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.ib_reg));
             for (int b = 0; b < nb; ++b) {
@@ -636,9 +672,9 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.n_active = n_active;
                 it.n_hot = n_hot_bs;
                 it.item_mask = item_mask;
-                it.chains = bs_chains.ptr + static_cast<size_t>(b) * std::max(n_hot_bs, 1);
-                it.blocks = bs_blocks.ptr + static_cast<size_t>(b) * max_blocks;
-                it.walk_begin = walk_begin.ptr + b;
+                it.chains = bs_chains[slot].ptr + static_cast<size_t>(b) * std::max(n_hot_bs, 1);
+                it.blocks = bs_blocks[slot].ptr + static_cast<size_t>(b) * max_blocks;
+                it.walk_begin = walk_begin[slot].ptr + b;
                 it.item_of_rank = item_of_rank.ptr;
                 it.tables = tables.ptr;
                 it.log2a = static_cast<float>(la);
@@ -665,6 +701,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 CU2REC_HIP(hipStreamWaitEvent(stream, ev_join, 0));
             }
             CU2REC_HIP(hipGetLastError());
+            CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));
             done += nb;
             continue;
         }
@@ -676,8 +713,8 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             launch_chains(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream, 0);
         }
         CU2REC_HIP(hipGetLastError());
+        CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));
         done += nb;
-        // the next batch reuses the key / value buffers: the stream orders it behind this batch's kernels
     }
 }
 

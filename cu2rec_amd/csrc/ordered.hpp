@@ -26,8 +26,13 @@ struct OrderedSchedule {
     int item_bits = 0;  // key = iteration_in_batch << item_bits | popularity_rank(item)
     int max_batch = 1;  // iterations scheduled (sampled + sorted) per pass
     DeviceBuffer<int> item_rank, item_of_rank;
-    DeviceBuffer<uint32_t> keys[2];
-    DeviceBuffer<uint64_t> vals[2];
+    // Two schedule slots: the sample stream is value independent, so batch j + 1 is sampled and sorted on a stream of
+    // its own while batch j's iterations run.  Per slot: the radix sort's two key / value buffers.
+    DeviceBuffer<uint32_t> keys[2][2];
+    DeviceBuffer<uint64_t> vals[2][2];
+    hipStream_t sched = nullptr;
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    bool slot_used[2] = {false, false};
     DeviceBuffer<unsigned char> temp;
     size_t temp_bytes = 0;
     // block-solve mode: items are ranked by their expected updates per iteration (sum over raters of 1 / degree);
@@ -38,9 +43,9 @@ struct OrderedSchedule {
     int qstart_ld = 0;
     SgdHyper tables_for{};   // hyper-parameters the decay tables were computed from
     bool tables_valid = false;
-    DeviceBuffer<int> chain_begin, walk_begin;
-    DeviceBuffer<BsChainDesc> bs_chains;
-    DeviceBuffer<BsBlockDesc> bs_blocks;
+    DeviceBuffer<int> chain_begin[2], walk_begin[2];
+    DeviceBuffer<BsChainDesc> bs_chains[2];
+    DeviceBuffer<BsBlockDesc> bs_blocks[2];
     DeviceBuffer<float> tables, Mbuf, basebuf, ebuf, qstart;
     hipStream_t side = nullptr;            // the walked chains of an iteration run beside its three phases
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
