@@ -87,6 +87,7 @@ SIGNATURES = {
     "cu2rec_hogwild_iters_per_launch": (C.c_int, [C.c_int]),
     "cu2rec_hogwild_resident": (C.c_int, [C.c_int]),
     "cu2rec_check_faults": (C.c_int, []),
+    "cu2rec_hogwild_resident_refusals": (C.c_int, []),
     "cu2rec_hogwild_resident_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "cu2rec_schedule_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "cu2rec_schedule_destroy": (None, [_P]),

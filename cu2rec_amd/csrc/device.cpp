@@ -483,6 +483,8 @@ int cu2rec_hogwild_iters_per_launch(int k) {
 
 int cu2rec_hogwild_resident(int policy) { return resident_policy(policy); }
 
+int cu2rec_hogwild_resident_refusals(void) { return resident_refusals(); }
+
 int cu2rec_check_faults(void) {
     return guarded([&] {
         require_device();

@@ -211,6 +211,7 @@ static void build_csr(const RatingsFile &r, int rows, int *indptr, int *indices,
     for (int k = 0; k < n; ++k) {
         const int u = r.user[k];
         if (u < 0 || r.item[k] < 0) fail(CU2REC_EINVAL, "cu2rec_csr_build: ids must be >= 1 in the file");
+        if (u >= rows) fail(CU2REC_EINVAL, "cu2rec_csr_build: user id beyond rows");
         if (u + 1 < next_user) fail(CU2REC_EINVAL, "cu2rec_csr_build: ratings must be sorted by userId");
         while (next_user <= u) indptr[next_user++] = k;  // users without ratings repeat the pointer
         indices[k] = r.item[k];
@@ -364,9 +365,14 @@ int cu2rec_ratings_load_binary(const char *path, cu2rec_ratings **out) {
             f.rows = h.rows;
             f.cols = h.cols;
             f.global_bias = h.global_bias;
+            // the file is data, not code we wrote a moment ago: every id must lie inside the header's shape, or the CSR
+            // build (indptr[rows + 1] in caller memory) and every kernel behind it would run past their arrays
+            ok = ok && h.rows >= 0 && h.cols >= 0;
+            for (size_t k = 0; ok && k < n; ++k)
+                ok = f.user[k] >= 0 && f.user[k] < h.rows && f.item[k] >= 0 && f.item[k] < h.cols;
         }
         std::fclose(fp);
-        if (!ok) fail(CU2REC_EIO, std::string("not a cu2rec ratings cache: ") + path);
+        if (!ok) fail(CU2REC_EIO, std::string("not a cu2rec ratings cache (bad magic, short file or ids outside its header's shape): ") + path);
         *out = new cu2rec_ratings{std::move(f)};
     });
 }

@@ -115,9 +115,14 @@ __device__ __forceinline__ void barrier_census(const ResidentArgs &ra, BarrierSh
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= kMaxXcc - 1;
+    // The per-XCD count must be visible before the top count can reach gridDim.x: the second add is a RELEASE (it may
+    // not overtake the first, which sits on another cache line), and a reader that has seen the full top count takes an
+    // ACQUIRE before it reads the per-XCD counts.  With two relaxed adds a workgroup could see "everybody has arrived"
+    // while the last per-XCD add was still in flight, undercount its XCD and open the barrier early.
     __hip_atomic_fetch_add(ra.words + kWCensus + xcc * kLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(ra.words + kWCensusTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ra.words + kWCensusTop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     bs->ok = spin_until(ra.words + kWCensusTop, gridDim.x, ra.status) ? 1 : 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     int n_xcds = 0;
     for (int x = 0; x < kMaxXcc; ++x) n_xcds += ld_relaxed(ra.words + kWCensus + x * kLine) != 0;
     bs->xcc = static_cast<int>(xcc);
@@ -463,6 +468,8 @@ struct DeviceState {
     hipEvent_t done = nullptr;        // end of the latest resident launch
     hipStream_t last_stream = nullptr;
     bool have_last = false;
+    bool cooperative = false;         // hipDeviceAttributeCooperativeLaunch
+    int refused = 0;                  // launches the runtime refused (grid not co-resident): those calls streamed
 };
 
 std::mutex g_mutex;
@@ -478,6 +485,9 @@ DeviceState &state_for_current_device() {
         hipDeviceProp_t prop;
         CU2REC_HIP(hipGetDeviceProperties(&prop, dev));
         s.cus = prop.multiProcessorCount;
+        int coop = 0;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) (void)hipGetLastError();
+        s.cooperative = coop != 0 && std::getenv("CU2REC_RESIDENT_PLAIN_LAUNCH") == nullptr;
         CU2REC_HIP(hipMalloc(reinterpret_cast<void **>(&s.words), (kBarrierWords + kLine) * sizeof(unsigned)));
         CU2REC_HIP(hipMemset(s.words, 0, (kBarrierWords + kLine) * sizeof(unsigned)));
         CU2REC_HIP(hipMalloc(reinterpret_cast<void **>(&s.sink), kSinkFloats * sizeof(float)));
@@ -587,6 +597,16 @@ bool plan_locked(int n_rows, int nslots, int n_iters, int update_items, DeviceSt
 
 }  // namespace
 
+int resident_refusals() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return dev < static_cast<int>(g_states.size()) ? g_states[dev].refused : 0;
+}
+
 bool resident_plan(int n_rows, int n_factors, int n_iters, int *blocks_out, int *users_per_group_out) {
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceState *s = nullptr;
@@ -610,7 +630,20 @@ bool resident_launch(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream)
     ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink};
     void *args[] = {&a, &ra};
     CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));  // counters start from zero
-    CU2REC_HIP(hipLaunchKernel(kVariants[variant].kernel, dim3(blocks), dim3(kResBlock), args, 0, stream));
+    // A cooperative launch: the runtime checks the grid against what can be co-resident and REFUSES a larger one up
+    // front (hipErrorCooperativeLaunchTooLarge) instead of letting it wait at its first barrier for workgroups that
+    // were never dispatched.  A refusal is not an error here: the call falls back to one launch per iteration, and the
+    // variant is not tried again on this device.  (What a launch-time check cannot see -- another process taking CUs
+    // while the grid runs -- is still caught by the barrier's timeout.)
+    const hipError_t launched = s.cooperative
+                                    ? hipLaunchCooperativeKernel(kVariants[variant].kernel, dim3(blocks), dim3(kResBlock), args, 0, stream)
+                                    : hipLaunchKernel(kVariants[variant].kernel, dim3(blocks), dim3(kResBlock), args, 0, stream);
+    if (launched != hipSuccess) {
+        (void)hipGetLastError();
+        s.usable[variant] = false;
+        ++s.refused;
+        return false;
+    }
     CU2REC_HIP(hipMemcpyAsync(s.host_status, s.words + kBarrierWords, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     CU2REC_HIP(hipEventRecord(s.done, stream));
     s.last_stream = stream;

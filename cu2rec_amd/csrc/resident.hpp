@@ -28,6 +28,9 @@ bool resident_plan(int n_rows, int n_factors, int n_iters, int *blocks, int *use
 // do not fit registers + LDS (policy and call length are not considered).
 bool resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group, int *lds_rows);
 
+// Launches the runtime refused on the current device because the grid could not be co-resident (those calls streamed).
+int resident_refusals();
+
 // Throws if an earlier resident launch on the current device gave up at a grid barrier (bounded spin).
 void resident_check_fault();
 

@@ -143,8 +143,13 @@ class ShardedSGD:
             self.engine.sgd(self.ratings, hyper, seed, iter0 + done, n, mode, update_items, self.user_offset)
             done += n
             self.since_sync += n
-            if self.since_sync >= self.sync_every and update_items:
-                self.exchange()
+            if self.since_sync >= self.sync_every:
+                # the period ends whether or not there is anything to exchange: with frozen items (is_train == false)
+                # no replica has moved, but the counter must still start over or n stays 0 forever
+                if update_items:
+                    self.exchange()
+                else:
+                    self.since_sync = 0
         return done
 
     def loss(self, ratings):

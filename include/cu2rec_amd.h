@@ -227,10 +227,14 @@ int cu2rec_hogwild_iters_per_launch(int k);
  * hogwild_iters_per_launch is 1; otherwise the call runs one streaming launch per iteration as before.
  * policy: 0 never, 1 auto (default: when it fits and a call covers >= 4 iterations), 2 whenever it fits;
  * CU2REC_RESIDENT=0|1|2 in the environment sets the initial value.  Returns the previous policy; other values query.
- * A resident launch assumes the GPU to itself (one workgroup per CU, all co-resident).  If it cannot get that, its
- * barrier gives up after 3 s and the next call into the library returns CU2REC_EHIP (once: the model state is
- * undefined after that, but the library stays usable, e.g. with policy 0). */
+ * A resident launch assumes the GPU to itself (one workgroup per CU, all co-resident).  It is a cooperative launch: a
+ * grid the runtime finds too large to be co-resident is refused up front and that call runs one streaming launch per
+ * iteration instead (cu2rec_hogwild_resident_refusals counts them) -- nothing is lost.  What a launch-time check cannot
+ * see (another process taking CUs while the grid runs) ends at the barrier's 3 s timeout: the next call into the library
+ * returns CU2REC_EHIP (once: the model state is undefined after that, but the library stays usable, e.g. with policy 0). */
 int cu2rec_hogwild_resident(int policy);
+/* resident launches refused at launch time on the current device since the process started (those calls streamed) */
+int cu2rec_hogwild_resident_refusals(void);
 /* Waits for the current device and reports a resident launch that gave up at its barrier (CU2REC_EHIP, once), without
  * doing any other work: the same check every SGD / loss entry point makes on its way in. */
 int cu2rec_check_faults(void);

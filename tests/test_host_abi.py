@@ -187,6 +187,16 @@ def test_threaded_reader_binary_cache_and_fallback(tmp_path):
     L.cu2rec_ratings_free(h)
     L.cu2rec_ratings_free(h2)
     assert L.cu2rec_ratings_load_binary(str(p).encode(), C.byref(h2)) == -2  # a text file is not a cache
+    # a cache whose ids do not fit its own header (corrupt or edited) is refused, not handed to the CSR build
+    raw = bytearray((tmp_path / "big.bin").read_bytes())
+    n_rec = len(rows)
+    header = len(raw) - 12 * n_rec
+    for column, bad in ((0, n_users + 5), (0, -3), (1, 1 << 30)):
+        mod = bytearray(raw)
+        at = header + column * 4 * n_rec + 4 * (n_rec // 2)
+        mod[at:at + 4] = int(bad).to_bytes(4, "little", signed=True)
+        (tmp_path / "bad.bin").write_bytes(bytes(mod))
+        assert L.cu2rec_ratings_load_binary(str(tmp_path / "bad.bin").encode(), C.byref(h2)) == -2
 
 
 def test_resident_geometry_arithmetic():

@@ -104,6 +104,30 @@ def test_single_rank_cadence_terminates_and_matches_oracle():
     assert job.loss(te)["n"] == te.nnz
 
 
+def test_frozen_items_run_longer_than_a_period_terminates():
+    """with update_items == False nothing is exchanged, but the period counter must still start over --
+    otherwise the loop asks the engine for 0 iterations forever once n_iters exceeds sync_every."""
+    tr, _ = synth.make_ratings(60, 30, 600, min_degree=2, seed=2)
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, 8)
+
+    class Counting(OracleEngine):
+        calls = []
+
+        def sgd(self, ratings, hyper, seed, iter0, n_iters, mode, update_items=True, user_offset=0):
+            assert n_iters > 0 and len(self.calls) < 50, "the loop must make progress"
+            self.calls.append((iter0, n_iters))
+            super().sgd(ratings, hyper, seed, iter0, n_iters, mode, update_items, user_offset)
+
+    eng = Counting(tr.rows, tr.cols, 8, tr.global_bias, P, Q, ub, ib)
+    job = ShardedSGD(eng, tr, sync_every=10)
+    assert job.run(HYPER, 42, 0, 25, cu.SGD_HOGWILD, update_items=False) == 25
+    assert eng.calls == [(0, 10), (10, 10), (20, 5)] and job.exchanges == 0
+    np.testing.assert_array_equal(eng.Q, Q)  # frozen
+    orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols), P, Q, ub, ib, tr.global_bias, HYPER,
+                       42, 0, 25, update_items=False)
+    np.testing.assert_allclose(eng.P, P, atol=1e-6)
+
+
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
