@@ -114,6 +114,18 @@ SIGNATURES = {
     "cu2rec_model_loss": (C.c_int, [_P, _P, _dp, _dp, _fp, _fp]),
     "cu2rec_train": (C.c_int, [_P, _P, C.POINTER(Config), _P, C.c_int, C.c_int, _P, C.POINTER(TrainStats)]),
     "cu2rec_shard_plan": (C.c_int, [C.c_int, C.c_int, _P]),
+    "cu2rec_comm_unique_id": (C.c_int, [_P]),
+    "cu2rec_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "cu2rec_comm_from_nccl": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "cu2rec_comm_from_callback": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "cu2rec_comm_destroy": (None, [_P]),
+    "cu2rec_shard_job_create": (C.c_int, [_P, _P, _P, C.c_int, _P, C.POINTER(_P)]),
+    "cu2rec_shard_job_destroy": (None, [_P]),
+    "cu2rec_shard_job_run": (C.c_int, [_P, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]),
+    "cu2rec_shard_job_exchange": (C.c_int, [_P]),
+    "cu2rec_shard_job_loss": (C.c_int, [_P, _P, _dp, _dp, _dp, _fp, _fp]),
+    "cu2rec_shard_job_info": (C.c_int, [_P, _ip, _ip, _dp, _dp, C.POINTER(C.c_size_t)]),
+    "cu2rec_train_sharded": (C.c_int, [_P, _P, C.POINTER(Config), C.c_int, C.c_int, _P, C.POINTER(TrainStats)]),
     "cu2rec_csr_slice": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _ip, _ip]),
     "cu2rec_items_delta_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
     "cu2rec_items_delta_apply_overlapped": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_float, _P]),

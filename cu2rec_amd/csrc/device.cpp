@@ -329,7 +329,7 @@ void DeviceModel::finish_swap() {
 }
 
 void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t seed, uint64_t iter0, int n_iters, int mode,
-                      int update_items, hipStream_t stream, bool defer_last_swap) {
+                      int update_items, hipStream_t stream, bool defer_last_swap, int user_offset) {
     require(train.rows <= rows && train.max_item < cols, "cu2rec_model_sgd: ratings exceed the model's shape");
     finish_swap();
     if (mode == CU2REC_SGD_PINGPONG) {
@@ -347,7 +347,7 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
         const bool swapped = sgd_update_pingpong(train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr,
                                                  ld, Q.ptr, Q_other.ptr, ldq, user_bias.ptr, item_bias.ptr,
                                                  item_bias_other.ptr, claim.ptr, global_bias, n_factors, h, seed, iter0,
-                                                 n_iters, update_items, 0, !defer_last_swap, stream);
+                                                 n_iters, update_items, user_offset, !defer_last_swap, stream);
         if (swapped) {  // Q / item_bias always name the current item side
             Q.swap(Q_other);
             item_bias.swap(item_bias_other);
@@ -361,7 +361,7 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
             train.schedule.reset(new OrderedSchedule(train.indptr.ptr, train.indices.ptr, train.rows, cols, train.nnz));
         sgd_update_ordered(*train.schedule, train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr,
                            ld, Q.ptr, ldq, user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters,
-                           update_items, 0, stream, mode == CU2REC_SGD_BLOCKSOLVE);
+                           update_items, user_offset, stream, mode == CU2REC_SGD_BLOCKSOLVE);
         return;
     }
     const void *pairs = nullptr;
@@ -374,8 +374,8 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
         pairs = train.pairs.ptr;
     }
     sgd_update(train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr, ld, Q.ptr, ldq,
-               user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters, mode, update_items, 0, stream,
-               pairs);
+               user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters, mode, update_items, user_offset,
+               stream, pairs);
 }
 
 void DeviceModel::loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq, float *mae, float *rmse,

@@ -67,8 +67,9 @@ struct DeviceModel {
                 const float *item_bias, float global_bias);
     void download(float *P, float *Q, float *user_bias, float *item_bias) const;
     // defer_last_swap (CU2REC_SGD_PINGPONG only): leave out the last iteration's swap; finish_swap() does it later
+    // user_offset: global id of row 0 when the model holds one shard of a user-sharded set (enters the sampler only)
     void sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t seed, uint64_t iter0, int n_iters, int mode,
-             int update_items, hipStream_t stream, bool defer_last_swap = false);
+             int update_items, hipStream_t stream, bool defer_last_swap = false, int user_offset = 0);
     void finish_swap();
     void loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq, float *mae, float *rmse,
               hipStream_t stream) const;

@@ -83,5 +83,10 @@ void launch_items_delta_pack_weighted(const float *Q, const float *ib, const flo
                                       const float *weight, int n_cols, int ldq, float *buf, hipStream_t stream);
 void launch_items_delta_apply(float *Q, float *ib, float *Q_base, float *ib_base, int n_cols, int ldq,
                               const float *buf, float scale, hipStream_t stream);
+// wire format of the exchange: n_cols * f row deltas then n_cols bias deltas, unpadded; weight (n_cols) may be null
+void launch_items_wire_pack(const float *Q, const float *ib, const float *Q_base, const float *ib_base, const float *weight,
+                            int n_cols, int f, int ldq, float *wire, hipStream_t stream);
+void launch_items_wire_apply(float *Q, float *ib, float *Q_base, float *ib_base, int n_cols, int f, int ldq, const float *wire,
+                             float scale, hipStream_t stream);
 
 }  // namespace cu2rec

@@ -1,0 +1,368 @@
+// User-sharded training, one process per GPU: the C++ driver behind cu2rec_train_sharded and bin/mf -g N.
+// Each rank owns a contiguous range of users (their CSR slice, their rows of P and user_bias) and a replica of the item
+// side.  Every sync_every iterations the replicas are reconciled: wire = [Q - Q_base | item_bias - ib_base] (row padding
+// stripped: I * (f + 1) floats, 10.8 MB for the ML-20M shape at f = 100), ONE ncclAllReduce(sum) over xGMI, then
+// Q = Q_base + scale * wire, which is also the new snapshot.  Sampler draws are keyed by the GLOBAL user id, so a shard
+// draws what the unsharded run draws.  The loss is an all-reduce of three doubles.  RCCL is resolved at run time
+// (dlopen: a copy PyTorch has already loaded is reused, otherwise /opt/rocm's), so the single-GPU library does not
+// depend on it.
+#include "sharded.hpp"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "kernels.hpp"
+#include "resident.hpp"
+#include "train_schedule.hpp"
+
+namespace cu2rec {
+
+namespace {
+
+// the few RCCL entry points used (rccl/rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclAllReduce, ncclCommDestroy)
+struct Rccl {
+    struct UniqueId {
+        char internal[128];
+    };
+    int (*GetUniqueId)(UniqueId *) = nullptr;
+    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {  // one already in the process (PyTorch's) first
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (h) break;
+        }
+        if (!h)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (h) break;
+            }
+        if (!h) {
+            r.why = std::string("cannot load librccl: ") + dlerror();
+            return;
+        }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
+        if (!r.ok) r.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+    });
+    if (!r.ok) fail(CU2REC_EUNSUPPORTED, "cu2rec_amd: RCCL is not available (" + r.why + ")");
+    return r;
+}
+
+void rccl_check(int code, const char *what) {
+    if (code == 0) return;
+    Rccl &r = rccl();
+    fail(CU2REC_EHIP, std::string("RCCL error in ") + what + ": " + (r.GetErrorString ? r.GetErrorString(code) : "?"));
+}
+
+constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclFloat64 = 8;  // rccl.h: ncclSum, ncclFloat32, ncclFloat64
+
+}  // namespace
+
+Comm::~Comm() {
+    if (nccl && owns_nccl) (void)rccl().CommDestroy(nccl);
+}
+
+void Comm::allreduce(void *buf, size_t count, bool is_double, hipStream_t stream) const {
+    if (count == 0 || (nranks == 1 && !nccl)) return;  // (a one-rank RCCL communicator exists for tests only)
+    if (nccl) {
+        rccl_check(rccl().AllReduce(buf, buf, count, is_double ? kNcclFloat64 : kNcclFloat32, kNcclSum, nccl, stream), "ncclAllReduce");
+        return;
+    }
+    require(fn != nullptr, "cu2rec_comm: no communicator behind a multi-rank job");
+    if (fn(ctx, buf, count, is_double ? 1 : 0, stream) != 0) fail(CU2REC_EHIP, "cu2rec_comm: the caller's all-reduce failed");
+}
+
+void comm_unique_id(void *id_out128) {
+    Rccl::UniqueId id;
+    rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+    std::memcpy(id_out128, id.internal, sizeof(id.internal));
+}
+
+Comm *comm_create_rccl(const void *id128, int rank, int nranks) {
+    require(id128 && nranks >= 1 && rank >= 0 && rank < nranks, "cu2rec_comm_create: bad argument");
+    require_device();
+    Comm *c = new Comm;
+    c->rank = rank;
+    c->nranks = nranks;
+    // CU2REC_RCCL_WORLD1=1: a real communicator even for one rank, so that a one-GPU box exercises ncclAllReduce
+    const char *force = std::getenv("CU2REC_RCCL_WORLD1");
+    if (nranks > 1 || (force && *force == '1')) {
+        Rccl::UniqueId id;
+        std::memcpy(id.internal, id128, sizeof(id.internal));
+        try {
+            rccl_check(rccl().CommInitRank(&c->nccl, nranks, id, rank), "ncclCommInitRank");
+        } catch (...) {
+            delete c;
+            throw;
+        }
+        c->owns_nccl = true;
+    }
+    return c;
+}
+
+Comm *comm_adopt_rccl(void *nccl_comm, int rank, int nranks) {
+    require(nranks >= 1 && rank >= 0 && rank < nranks && (nccl_comm || nranks == 1), "cu2rec_comm_from_nccl: bad argument");
+    if (nranks > 1) (void)rccl();
+    Comm *c = new Comm;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->nccl = nranks > 1 ? nccl_comm : nullptr;
+    return c;
+}
+
+Comm *comm_from_callback(cu2rec_allreduce_fn fn, void *ctx, int rank, int nranks) {
+    require(nranks >= 1 && rank >= 0 && rank < nranks && (fn || nranks == 1), "cu2rec_comm_from_callback: bad argument");
+    Comm *c = new Comm;
+    c->rank = rank;
+    c->nranks = nranks;
+    c->fn = fn;
+    c->ctx = ctx;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------------------ ShardJob
+ShardJob::ShardJob(Comm &comm_, DeviceModel &model_, const DeviceCsr &train_, int user_offset_,
+                   const cu2rec_shard_options &opt)
+    : comm(comm_), model(model_), train(train_), user_offset(user_offset_), sync_every(opt.sync_every), merge(opt.merge) {
+    require(train.rows <= model.rows && train.max_item < model.cols, "cu2rec_shard_job: ratings exceed the model's shape");
+    require(merge == CU2REC_MERGE_MEAN || merge == CU2REC_MERGE_WEIGHTED || merge == CU2REC_MERGE_SUM, "cu2rec_shard_job: unknown merge");
+    require(user_offset >= 0, "cu2rec_shard_job: negative user offset");
+    require_device();
+    const size_t nq = static_cast<size_t>(model.cols) * model.ldq;
+    Q_base.allocate(std::max<size_t>(nq, 4));
+    ib_base.allocate(std::max(model.cols, 1));
+    wire.allocate(std::max<size_t>(static_cast<size_t>(model.cols) * (model.n_factors + 1), 4));
+    sums.allocate(4);
+    CU2REC_HIP(hipMemcpy(Q_base.ptr, model.Q.ptr, nq * sizeof(float), hipMemcpyDeviceToDevice));
+    CU2REC_HIP(hipMemcpy(ib_base.ptr, model.item_bias.ptr, static_cast<size_t>(model.cols) * sizeof(float), hipMemcpyDeviceToDevice));
+    // population totals (the epoch length) and, for the weighted merge, every item's expected updates per iteration
+    double totals[2] = {static_cast<double>(train.users_with_ratings), static_cast<double>(train.nnz)};
+    CU2REC_HIP(hipMemcpy(sums.ptr, totals, sizeof(totals), hipMemcpyHostToDevice));
+    comm.allreduce(sums.ptr, 2, true, nullptr);
+    CU2REC_HIP(hipMemcpy(totals, sums.ptr, sizeof(totals), hipMemcpyDeviceToHost));
+    users_total = totals[0];
+    nnz_total = totals[1];
+    if (sync_every <= 0)  // "each epoch" (north star): one epoch = nnz / users iterations, SURVEY.md section 8e
+        sync_every = std::max(1, static_cast<int>(std::lround(nnz_total / std::max(users_total, 1.0))));
+    if (merge == CU2REC_MERGE_WEIGHTED && comm.nranks > 1) {
+        // w_k[y] = rate_k[y] / sum_j rate_j[y], rate = sum over the shard's raters of 1 / degree (host, double: the same
+        // bits every run); items nobody rates anywhere keep weight 1 / N (their delta is zero anyway)
+        std::vector<int> indptr(static_cast<size_t>(train.rows) + 1), indices(static_cast<size_t>(std::max(train.nnz, 1)));
+        CU2REC_HIP(hipMemcpy(indptr.data(), train.indptr.ptr, indptr.size() * sizeof(int), hipMemcpyDeviceToHost));
+        if (train.nnz) CU2REC_HIP(hipMemcpy(indices.data(), train.indices.ptr, static_cast<size_t>(train.nnz) * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<double> rate(static_cast<size_t>(std::max(model.cols, 1)), 0.0);
+        for (int u = 0; u < train.rows; ++u) {
+            const int low = indptr[u], high = indptr[u + 1];
+            for (int k = low; k < high; ++k) rate[indices[k]] += 1.0 / (high - low);
+        }
+        DeviceBuffer<double> all(rate.size());
+        all.upload(rate.data(), rate.size());
+        comm.allreduce(all.ptr, rate.size(), true, nullptr);
+        std::vector<double> total(rate.size());
+        CU2REC_HIP(hipDeviceSynchronize());
+        all.download(total.data(), total.size());
+        std::vector<float> w(rate.size());
+        for (size_t y = 0; y < rate.size(); ++y) w[y] = static_cast<float>(total[y] > 0 ? rate[y] / total[y] : 1.0 / comm.nranks);
+        weight.allocate(w.size());
+        weight.upload(w.data(), w.size());
+    }
+}
+
+float ShardJob::scale() const {
+    return merge == CU2REC_MERGE_MEAN ? 1.f / static_cast<float>(comm.nranks) : 1.f;  // weighted: the weights sum to one
+}
+
+void ShardJob::exchange(hipStream_t stream) {
+    since_sync = 0;
+    if (comm.nranks == 1 && !comm.nccl) return;
+    launch_items_wire_pack(model.Q.ptr, model.item_bias.ptr, Q_base.ptr, ib_base.ptr, weight.ptr, model.cols, model.n_factors,
+                           model.ldq, wire.ptr, stream);
+    CU2REC_HIP(hipGetLastError());
+    comm.allreduce(wire.ptr, static_cast<size_t>(model.cols) * (model.n_factors + 1), false, stream);
+    launch_items_wire_apply(model.Q.ptr, model.item_bias.ptr, Q_base.ptr, ib_base.ptr, model.cols, model.n_factors, model.ldq,
+                            wire.ptr, scale(), stream);
+    CU2REC_HIP(hipGetLastError());
+    ++exchanges;
+}
+
+void ShardJob::run(const cu2rec_hyper &h, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
+                   hipStream_t stream) {
+    require(n_iters >= 0, "cu2rec_shard_job_run: bad iteration count");
+    require(mode != CU2REC_SGD_PINGPONG, "cu2rec_shard_job_run: the ping-pong mode swaps item buffers and is single-GPU only");
+    int done = 0;
+    while (done < n_iters) {
+        const int n = std::min(n_iters - done, sync_every - since_sync);
+        model.sgd(train, h, seed, iter0 + static_cast<uint64_t>(done), n, mode, update_items, stream, false, user_offset);
+        done += n;
+        since_sync += n;
+        if (since_sync >= sync_every) {
+            // the period ends whether or not anything moved: with frozen items nothing is exchanged, but the counter
+            // starts over (or n would stay 0 for ever)
+            if (update_items) exchange(stream);
+            else since_sync = 0;
+        }
+    }
+}
+
+void ShardJob::loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq, double *n_total, float *mae, float *rmse,
+                    hipStream_t stream) {
+    double host[3] = {0.0, 0.0, static_cast<double>(ratings.nnz)};
+    model.loss(ratings, &host[0], &host[1], nullptr, nullptr, stream);
+    if (comm.nranks > 1) {
+        CU2REC_HIP(hipMemcpyAsync(sums.ptr, host, sizeof(host), hipMemcpyHostToDevice, stream));
+        comm.allreduce(sums.ptr, 3, true, stream);
+        CU2REC_HIP(hipMemcpyAsync(host, sums.ptr, sizeof(host), hipMemcpyDeviceToHost, stream));
+        CU2REC_HIP(hipStreamSynchronize(stream));
+    }
+    if (sum_abs) *sum_abs = host[0];
+    if (sum_sq) *sum_sq = host[1];
+    if (n_total) *n_total = host[2];
+    if (mae) *mae = static_cast<float>(host[0] / host[2]);              // loss.cu:189
+    if (rmse) *rmse = static_cast<float>(std::sqrt(host[1] / host[2]));
+}
+
+// train() (training.h:12-15) over all ranks: the same observable schedule as cu2rec_train -- loss on train and test at
+// i == 0, every check_error and last, the TRAIN: / TEST: lines (rank 0), patience / learning-rate decay on the GLOBAL
+// test RMSE (identical on every rank: the loss sums are all-reduced), cfg.learning_rate / cfg.cur_iterations updated.
+void train_sharded(ShardJob &job, const DeviceCsr &test, cu2rec_config &cfg, int mode, bool verbose, float *losses,
+                   cu2rec_train_stats *stats) {
+    require(cfg.n_factors == job.model.n_factors, "cu2rec_train_sharded: cfg.n_factors differs from the model's");
+    require(test.rows <= job.model.rows && test.max_item < job.model.cols,
+            "cu2rec_train_sharded: test ratings name users/items the model does not have");
+    hipStream_t stream = nullptr;
+    const uint64_t seed = static_cast<uint64_t>(static_cast<uint32_t>(cfg.seed));
+    train_schedule(
+        cfg, verbose, job.comm.rank == 0, job.users_total, losses, stats, stream,
+        [&](const cu2rec_hyper &h, uint64_t first, int n, hipStream_t s) {
+            job.run(h, seed, first, n, mode, cfg.is_train, s);
+            // a loss check follows: every replica must hold the same item side (an exchange out of cadence, like the
+            // Python driver's exchange(final=True))
+            if (cfg.is_train && job.since_sync > 0) job.exchange(s);
+        },
+        [&](bool on_train, float *mae, float *rmse) {
+            job.loss(on_train ? job.train : test, nullptr, nullptr, nullptr, mae, rmse, stream);
+        },
+        [] {});
+}
+
+}  // namespace cu2rec
+
+using namespace cu2rec;
+
+extern "C" {
+
+int cu2rec_comm_unique_id(void *id_out) {
+    return guarded([&] {
+        require(id_out, "cu2rec_comm_unique_id: null argument");
+        comm_unique_id(id_out);
+    });
+}
+
+int cu2rec_comm_create(const void *unique_id, int rank, int nranks, cu2rec_comm **out) {
+    return guarded([&] {
+        require(out, "out is null");
+        *out = nullptr;
+        *out = new cu2rec_comm{comm_create_rccl(unique_id, rank, nranks)};
+    });
+}
+
+int cu2rec_comm_from_nccl(void *nccl_comm, int rank, int nranks, cu2rec_comm **out) {
+    return guarded([&] {
+        require(out, "out is null");
+        *out = nullptr;
+        *out = new cu2rec_comm{comm_adopt_rccl(nccl_comm, rank, nranks)};
+    });
+}
+
+int cu2rec_comm_from_callback(cu2rec_allreduce_fn fn, void *ctx, int rank, int nranks, cu2rec_comm **out) {
+    return guarded([&] {
+        require(out, "out is null");
+        *out = nullptr;
+        *out = new cu2rec_comm{comm_from_callback(fn, ctx, rank, nranks)};
+    });
+}
+
+void cu2rec_comm_destroy(cu2rec_comm *c) {
+    if (!c) return;
+    delete c->impl;
+    delete c;
+}
+
+int cu2rec_shard_job_create(cu2rec_comm *comm, cu2rec_model *model, const cu2rec_csr *train, int user_offset,
+                            const cu2rec_shard_options *options, cu2rec_shard_job **out) {
+    return guarded([&] {
+        require(comm && comm->impl && model && train && out, "cu2rec_shard_job_create: null argument");
+        *out = nullptr;
+        cu2rec_shard_options opt{0, CU2REC_MERGE_MEAN};
+        if (options) opt = *options;
+        *out = new cu2rec_shard_job(*comm->impl, unwrap(model), unwrap(train), user_offset, opt);
+    });
+}
+
+void cu2rec_shard_job_destroy(cu2rec_shard_job *job) { delete job; }
+
+int cu2rec_shard_job_run(cu2rec_shard_job *job, const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters,
+                         int mode, int update_items) {
+    return guarded([&] {
+        require(job && hyper, "cu2rec_shard_job_run: null argument");
+        job->impl.run(*hyper, seed, iter0, n_iters, mode, update_items, nullptr);
+    });
+}
+
+int cu2rec_shard_job_exchange(cu2rec_shard_job *job) {
+    return guarded([&] {
+        require(job, "cu2rec_shard_job_exchange: null argument");
+        if (job->impl.since_sync > 0) job->impl.exchange(nullptr);
+    });
+}
+
+int cu2rec_shard_job_loss(cu2rec_shard_job *job, const cu2rec_csr *ratings, double *sum_abs, double *sum_sq,
+                          double *n_total, float *mae, float *rmse) {
+    return guarded([&] {
+        require(job && ratings, "cu2rec_shard_job_loss: null argument");
+        job->impl.loss(unwrap(ratings), sum_abs, sum_sq, n_total, mae, rmse, nullptr);
+    });
+}
+
+int cu2rec_shard_job_info(const cu2rec_shard_job *job, int *sync_every, int *exchanges, double *users_total,
+                          double *nnz_total, size_t *wire_bytes) {
+    return guarded([&] {
+        require(job, "cu2rec_shard_job_info: null argument");
+        if (sync_every) *sync_every = job->impl.sync_every;
+        if (exchanges) *exchanges = job->impl.exchanges;
+        if (users_total) *users_total = job->impl.users_total;
+        if (nnz_total) *nnz_total = job->impl.nnz_total;
+        if (wire_bytes) *wire_bytes = static_cast<size_t>(job->impl.model.cols) * (job->impl.model.n_factors + 1) * sizeof(float);
+    });
+}
+
+int cu2rec_train_sharded(cu2rec_shard_job *job, const cu2rec_csr *test, cu2rec_config *cfg, int mode, int verbose,
+                         float *losses, cu2rec_train_stats *stats) {
+    return guarded([&] {
+        require(job && test && cfg, "cu2rec_train_sharded: null argument");
+        train_sharded(job->impl, unwrap(test), *cfg, mode, verbose != 0, losses, stats);
+    });
+}
+
+}  // extern "C"

@@ -4,7 +4,10 @@
       -m cu2rec_amd.mf_mgpu -c ml.cfg [-m hogwild|ordered] [--sync-every K] [--merge mean|sum] train.csv test.csv
 
 Same stdout lines and the same five output CSVs as bin/mf (mf.cu:16-99); rank 0 prints and writes.
-Ratings are sharded by user (cu2rec_amd/parallel.py); with one process it is bin/mf itself.
+A thin launcher: ratings are sharded by user and trained by the C++ driver (cu2rec_amd/csrc/sharded.cpp,
+cu2rec_train_sharded: ncclAllReduce of the item deltas each period); this script only starts the ranks' library calls,
+hands rank 0's ncclUniqueId around and gathers the user side for the output files.  `bin/mf -g N` is the same thing
+without Python.
 """
 import argparse
 import os
@@ -16,7 +19,7 @@ import numpy as np
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="cu2rec_amd.mf_mgpu")
     ap.add_argument("-c", dest="config", default=None)
-    ap.add_argument("-m", dest="mode", default="hogwild", choices=["hogwild", "ordered", "serial"])
+    ap.add_argument("-m", dest="mode", default="hogwild", choices=["hogwild", "ordered", "blocksolve", "serial"])
     ap.add_argument("--sync-every", type=int, default=0)
     ap.add_argument("--merge", default="weighted", choices=["mean", "sum", "weighted"])
     ap.add_argument("train")
@@ -27,7 +30,7 @@ def main(argv=None):
     import torch.distributed as dist
 
     import cu2rec_amd as cu
-    from cu2rec_amd.parallel import train_sharded
+    from cu2rec_amd.sharded import Comm, share_through_torch, train_sharded
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -44,8 +47,9 @@ def main(argv=None):
     cfg = cu.read_config(args.config) if args.config else cu.default_config()
     if rank == 0:
         cu.print_config(cfg)
-    P, Q, losses, ub, ib, (u0, u1) = train_sharded(train, test, cfg, mode=args.mode, sync_every=args.sync_every,
-                                                   merge=args.merge, verbose=True, device=device)
+    comm = Comm(rank, world, share=share_through_torch(device) if world > 1 else None)
+    P, Q, losses, ub, ib, (u0, u1), _ = train_sharded(comm, train, test, cfg, mode=args.mode, sync_every=args.sync_every,
+                                                      merge=args.merge, verbose=True)
     # gather the user side on rank 0 (rows are contiguous per rank)
     if world > 1:
         parts_P, parts_ub = [None] * world, [None] * world
@@ -61,6 +65,7 @@ def main(argv=None):
         cu.writeToFile(parent, base, "user_bias", ub, train.rows, 1, f)
         cu.writeToFile(parent, base, "item_bias", ib, train.cols, 1, f)
         cu.writeToFile(parent, base, "global_bias", np.array([train.global_bias], np.float32), 1, 1, f)
+    comm.close()
     if world > 1:
         dist.destroy_process_group()
     return 0

@@ -384,6 +384,58 @@ int cu2rec_item_update_rates(const int *indptr, const int *indices, int n_rows, 
 int cu2rec_items_delta_apply(float *Q, float *item_bias, float *Q_base, float *ib_base, int n_cols, int ldq,
                              const float *buf, float scale, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * User-sharded training on several GPUs, ONE PROCESS PER GPU (the reference is single device; the interface extended
+ * is train(), training.h:12-15).  Each rank owns a contiguous user range -- its CSR slice (cu2rec_csr_slice), a model
+ * whose P / user_bias cover the local users and whose Q / item_bias are a replica of the whole item side -- and every
+ * sync_every iterations the replicas are reconciled by ONE sum all-reduce of the item deltas in their wire format,
+ * n_cols * (n_factors + 1) floats without row padding: Q = Q_base + scale * sum_k w_k (Q_k - Q_base).  Sampler draws
+ * are keyed by the global user id (user_offset), so a shard draws what the unsharded run draws.
+ *
+ * The communicator is RCCL over xGMI (resolved at run time with dlopen: a copy already in the process -- PyTorch's -- is
+ * reused): created here from an ncclUniqueId the caller distributes (cu2rec_comm_unique_id on rank 0, 128 bytes), or an
+ * ncclComm_t the caller already owns, handed in as void*.  For tests there is a callback form: the caller's own
+ * in-place sum all-reduce on a device buffer (count elements of float, or double when is_double), ordered on `stream`
+ * or synchronising it; return 0 on success.  Every rank must make the same sequence of job calls.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct cu2rec_comm cu2rec_comm;
+typedef int (*cu2rec_allreduce_fn)(void *ctx, void *device_buf, size_t count, int is_double, void *stream);
+int cu2rec_comm_unique_id(void *id_out /* 128 bytes */);
+int cu2rec_comm_create(const void *unique_id, int rank, int nranks, cu2rec_comm **out); /* ncclCommInitRank on the current device */
+int cu2rec_comm_from_nccl(void *nccl_comm, int rank, int nranks, cu2rec_comm **out);    /* not owned */
+int cu2rec_comm_from_callback(cu2rec_allreduce_fn fn, void *ctx, int rank, int nranks, cu2rec_comm **out);
+void cu2rec_comm_destroy(cu2rec_comm *comm);
+
+typedef enum cu2rec_merge {
+    CU2REC_MERGE_MEAN = 0,     /* scale 1 / nranks */
+    CU2REC_MERGE_WEIGHTED = 1, /* per item: w_k[y] = rank k's share of the item's expected updates per iteration */
+    CU2REC_MERGE_SUM = 2       /* scale 1: diverges when many ranks update the same items many times per period */
+} cu2rec_merge;
+typedef struct cu2rec_shard_options {
+    int sync_every; /* iterations between exchanges; 0 = one epoch = round(nnz / users) of the whole population */
+    int merge;      /* cu2rec_merge */
+} cu2rec_shard_options;
+
+typedef struct cu2rec_shard_job cu2rec_shard_job;
+/* model and train must outlive the job; options may be NULL (epoch cadence, mean). Collective: all ranks call it. */
+int cu2rec_shard_job_create(cu2rec_comm *comm, cu2rec_model *model, const cu2rec_csr *train, int user_offset,
+                            const cu2rec_shard_options *options, cu2rec_shard_job **out);
+void cu2rec_shard_job_destroy(cu2rec_shard_job *job);
+/* n_iters iterations on the local shard, exchanging every sync_every iterations (the cadence runs across calls) */
+int cu2rec_shard_job_run(cu2rec_shard_job *job, const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters,
+                         int mode, int update_items);
+/* an exchange out of cadence (if anything happened since the last one): every replica equal afterwards */
+int cu2rec_shard_job_exchange(cu2rec_shard_job *job);
+/* MAE / RMSE over all ranks' slices of `ratings` (all-reduce of sum |e|, sum e^2, n) */
+int cu2rec_shard_job_loss(cu2rec_shard_job *job, const cu2rec_csr *ratings, double *sum_abs, double *sum_sq,
+                          double *n_total, float *mae, float *rmse);
+int cu2rec_shard_job_info(const cu2rec_shard_job *job, int *sync_every, int *exchanges, double *users_total,
+                          double *nnz_total, size_t *wire_bytes);
+/* cu2rec_train over all ranks: same schedule, same stdout lines (rank 0 prints), patience / learning-rate decay on the
+ * GLOBAL test RMSE; `test` is the rank's slice of the test set; stats->updates counts the whole population. */
+int cu2rec_train_sharded(cu2rec_shard_job *job, const cu2rec_csr *test, cu2rec_config *cfg, int mode, int verbose,
+                         float *losses, cu2rec_train_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif
