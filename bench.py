@@ -4,22 +4,24 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one reference iteration: one SGD update for every user with at least one rating
-(sgd.cu:27-37).  The library is called with 500 iterations at a time, the reference's stretch between two
-loss checks (N > 1: one exchange period);
-such a call is ONE resident launch (user rows in the register file, a grid barrier between
-iterations: cu2rec_amd/csrc/resident.hip) when the rows fit, else one launch per iteration.
-Inputs (CSR, P, Q, biases) are resident in HBM before the timed region.  For N > 1 every rank holds its own
-ML-20M-sized user population (weak scaling; same item set) and the replicas of Q / item_bias are
-reconciled by one RCCL all-reduce every `--sync-every` steps (default: one epoch = nnz / users
-steps), inside the timed region.
+A "step" is one reference iteration: one SGD update for every user with at least one rating (sgd.cu:27-37).
+`value` is measured in the mode that meets the north-star tolerance -- `blocksolve`: mf_sequential.cu's semantics with
+the hot item chains solved block-wise (cu2rec_amd/csrc/blocksolve.hip), within 1e-4 test RMSE of the sequential result
+(`rmse_gap_vs_sequential` in the line, taken at equal iterations against the exact ordered mode) -- and the racy
+Hogwild modes (the reference GPU kernel's own semantics: resident launches, streaming launches) are reported beside it
+with THEIR gap.  Inputs (CSR, P, Q, biases) are resident in HBM before the timed region.  The timed region is exactly
+K steps between barrier + device synchronisation; a short region (< 0.25 s) is repeated and the median reported.
+
+N > 1: one process per GPU, ONE dataset whose users are sharded across the ranks (strong scaling, BASELINE.json
+configs[3]; --scaling weak gives every rank its own full-size population), trained by the C++ driver
+(cu2rec_amd/csrc/sharded.cpp): the replicas of Q / item_bias are reconciled by one ncclAllReduce of the unpadded item
+deltas every --sync-every steps (default one epoch = nnz / users), inside the timed region.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     HBM roofline of the SGD kernel: algorithmic bytes per launch (16 f + 32 per update,
-               SURVEY.md section 8d) / average kernel duration measured here with HIP events.
-  cpu_baseline the reference's own CPU twin (oracle/_ref/mf_cpu, kind "reference") timed on a
-               bounded sample of the same workload on this box's host cores, plus the oracle port
-               with the counter-based sampler ("port").
+  roofline     for the timed mode: algorithmic bytes (16 f + 32 per update) / duration measured
+               here with HIP events on the launch stream; frac <= 1 by construction.  Per-kernel durations: profiles/.
+  cpu_baseline the reference's own CPU twin (oracle/_ref/mf_cpu, kind "reference") timed on a bounded sample of the
+               same workload on this box's host cores, plus the oracle port with the counter-based sampler ("port").
 """
 import argparse
 import json
@@ -35,7 +37,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+GATHER_PEAK_GBS = 8600.0     # same guide, "Indexed rows": random rows of a table that lives in the Infinity Cache
 
 
 def load_dataset(name, seed, rank, barrier):
@@ -117,32 +120,39 @@ def cpu_baseline(train, test, f, hyper, budget_s=12.0):
     return out
 
 
-def measured_traffic(workload, f, name):
-    """HBM bytes per launch of the SGD kernel from the committed rocprofv3 PMC passes (profiles/), priced as
-    MI355X_MICROARCH.md prescribes (separate FETCH_SIZE / WRITE_SIZE passes, KiB units, FETCH_SIZE doubled on
-    gfx950).  Counters cannot be read from inside this process, so the figure is the latest committed one for
-    this exact workload / kernel; None if there is none."""
-    import glob
-    tag = "%s_f%d" % (workload.replace("-", ""), f)
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % tag)), reverse=True):
-        try:
-            for kernel, k in json.load(open(path)).items():
-                if name in kernel and "hbm_bytes_per_launch_corrected" in k:
-                    return {"bytes_per_launch": k["hbm_bytes_per_launch_corrected"],
-                            "source": os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                      "passes; raw %.1f MB, FETCH_SIZE x2 gfx950 correction applied)"
-                                      % (k["hbm_bytes_per_launch_raw"] / 1e6)}
-        except (OSError, ValueError):
-            continue
-    return None
-
-
 def log(msg):
     sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - T_START, msg))
     sys.stderr.flush()
 
 
 T_START = time.perf_counter()
+
+
+class HipEvents:
+    """HIP events on the stream the library launches on (the null stream): hipEventRecord / hipEventElapsedTime."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+
+    def new(self):
+        e = self.C.c_void_p()
+        assert self.hip.hipEventCreate(self.C.byref(e)) == 0
+        return e
+
+    def record(self, e):
+        assert self.hip.hipEventRecord(e, None) == 0
+
+    def ms(self, a, b):
+        assert self.hip.hipEventSynchronize(b) == 0
+        out = self.C.c_float()
+        assert self.hip.hipEventElapsedTime(self.C.byref(out), a, b) == 0
+        return float(out.value)
 
 
 def main():
@@ -156,19 +166,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--workload", default="ml-20m", choices=["ml-100k", "ml-1m", "ml-20m", "ml-25m", "netflix"])
     ap.add_argument("--factors", type=int, default=100)
-    ap.add_argument("--mode", default="hogwild", choices=["hogwild", "serial", "ordered"])
+    ap.add_argument("--mode", default="blocksolve", choices=["blocksolve", "hogwild", "serial", "ordered"])
     ap.add_argument("--sync-every", type=int, default=0, help="steps between item-factor all-reduces (0 = one epoch)")
-    ap.add_argument("--merge", default="mean", choices=["mean", "sum", "weighted"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank holds its own full-size user population (default); strong: ONE dataset, "
-                         "users sharded across the ranks (BASELINE.json configs[3])")
+    ap.add_argument("--merge", default="weighted", choices=["mean", "sum", "weighted"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="strong (default): ONE dataset, users sharded across the ranks (BASELINE.json configs[3]); weak: "
+                         "every rank holds its own full-size user population")
     ap.add_argument("--seed", type=int, default=20240917)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-samples", type=int, default=200)
-    ap.add_argument("--iters-per-launch", type=int, default=1,
-                    help="Hogwild launch blocking (opt-in, not the reference cadence): updates per user per launch")
-    ap.add_argument("--ordered-steps", type=int, default=128,
-                    help="extra (untimed for `value`) pass in the exact ordered mode, reported beside the headline; 0 = skip")
+    ap.add_argument("--no-side-modes", action="store_true", help="skip the untimed legs (Hogwild, ordered, loss kernel)")
     args = ap.parse_args()
 
     import torch
@@ -183,8 +189,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the cu2rec_amd hot path has no CPU fallback")
-    # CU2REC_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing check on a 1-GPU box); the real
-    # multi-GPU run is backend nccl (= RCCL over xGMI), one rank per GPU
+    # CU2REC_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing check on a 1-GPU box; the item exchange then
+    # goes through the host); the real multi-GPU run is RCCL over xGMI, one rank per GPU
     backend = os.environ.get("CU2REC_BENCH_BACKEND", "nccl")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
@@ -204,228 +210,215 @@ def main():
                 dist.barrier()
 
     import cu2rec_amd as cu
-    from cu2rec_amd.engine import DeviceRatings, Engine
-    from cu2rec_amd.parallel import ShardedSGD
-
+    from cu2rec_amd import sharded
+    from cu2rec_amd._lib import check
+    L = cu.lib()
+    check(L.cu2rec_set_device(dev_index))
     log("torch + library loaded, device %s" % torch.cuda.get_device_name(device))
     if world > 1 and backend != "nccl":
-        cu.lib().cu2rec_hogwild_resident(0)  # ranks share a GPU here: a resident launch needs the GPU to itself
-    train, test = load_dataset(args.workload, args.seed, rank, barrier)
-    log("dataset ready: %d users, %d items, %d train ratings" % (train.rows, train.cols, train.nnz))
+        L.cu2rec_hogwild_resident(0)  # ranks share a GPU here: a resident launch needs the GPU to itself
+    full_train, full_test = load_dataset(args.workload, args.seed, rank, barrier)
+    log("dataset ready: %d users, %d items, %d train ratings" % (full_train.rows, full_train.cols, full_train.nnz))
     f = args.factors
     hyper = (0.01, 0.02, 0.02, 0.02, 0.02)  # preprocessing/create_config.py:25-32
-    # iterations per cu2rec_sgd_update call: N > 1 -> the exchange period (default one epoch = nnz / users iterations);
-    # N = 1 -> nothing to exchange: 500 per call, the stretch between two loss checks of the reference's loop
-    # (check_error = 500, config.h:41-51, training.cu:118) and what cu2rec_train issues
+    train, test, user_offset = full_train, full_test, 0
     if world > 1:
-        sync_every = args.sync_every or max(1, int(round(train.nnz / max(int(np.count_nonzero(np.diff(train.indptr))), 1))))
-    else:
-        sync_every = args.sync_every or 500
-    user_offset = rank * train.rows  # weak scaling: rank r's users are users [r * rows, (r+1) * rows) of the population
-    if args.scaling == "strong" and world > 1:
-        from cu2rec_amd.parallel import plan_users
-        bounds = plan_users(train.rows, world)
-        user_offset = bounds[rank]
-        train, test = train.slice_users(bounds[rank], bounds[rank + 1]), test.slice_users(bounds[rank], bounds[rank + 1])
+        if args.scaling == "strong":
+            user_offset, _, train, test = sharded.shard_of(full_train, full_test, rank, world)
+        else:
+            user_offset = rank * full_train.rows  # rank r's users are users [r * rows, (r + 1) * rows) of the population
     users_active = int(np.count_nonzero(np.diff(train.indptr)))
 
-    eng = Engine(train.rows, train.cols, f, train.global_bias, device=device)
-    d_train, d_test = DeviceRatings(train, device), DeviceRatings(test, device)
-    rates = cu.api.item_update_rates(train) if args.merge == "weighted" else None
-    job = ShardedSGD(eng, d_train, user_offset=user_offset, sync_every=sync_every, merge=args.merge, item_rates=rates)
-    if args.iters_per_launch > 1:
-        cu.lib().cu2rec_hogwild_iters_per_launch(args.iters_per_launch)
-    mode = {"hogwild": cu.SGD_HOGWILD, "serial": cu.SGD_SERIAL, "ordered": cu.SGD_ORDERED}[args.mode]
-    log("model + ratings resident in HBM")
+    # the communicator of the data path: RCCL created by the library itself (rank 0's id broadcast through torch), or the
+    # gloo debugging aid as a callback
+    if world > 1 and backend != "nccl":
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+        def host_allreduce(ctx, buf, count, is_double, stream):
+            host = np.empty(count, np.float64 if is_double else np.float32)
+            if hip.hipDeviceSynchronize() != 0 or hip.hipMemcpy(host.ctypes.data, buf, host.nbytes, 2) != 0:
+                return 1
+            dist.all_reduce(torch.from_numpy(host))
+            return 0 if hip.hipMemcpy(buf, host.ctypes.data, host.nbytes, 1) == 0 else 1
+        comm = sharded.Comm(rank, world, allreduce=host_allreduce)
+    else:
+        comm = sharded.Comm(rank, world, share=sharded.share_through_torch(device) if world > 1 else None)
+
+    def fresh_model():
+        if world > 1 and args.scaling == "strong":  # every rank keeps its slice of the reference's seed-42 initialisation
+            P0 = cu.api.initialize_normal_array(full_train.rows * f, f).reshape(full_train.rows, f)
+            ub0 = cu.api.initialize_normal_array(full_train.rows, f)
+            u0, u1 = user_offset, user_offset + train.rows
+            return cu.Model(train.rows, train.cols, f, train.global_bias, P=P0[u0:u1], user_bias=ub0[u0:u1])
+        return cu.Model(train.rows, train.cols, f, train.global_bias)
+
+    model = fresh_model()
+    d_train, d_test = cu.DeviceCSR(train), cu.DeviceCSR(test)
+    # N = 1: nothing to exchange -- calls of 500 iterations, the stretch between two loss checks of the reference's loop
+    # (check_error = 500, config.h:41-51, training.cu:118) and what cu2rec_train issues
+    job = sharded.ShardJob(comm, model, d_train, user_offset=user_offset, sync_every=args.sync_every if world > 1 else 500,
+                           merge=args.merge)
+    info = job.info()
+    mode = args.mode
+    log("model + ratings resident in HBM; mode %s, sync every %d" % (mode, info["sync_every"]))
     rmse0 = job.loss(d_test)["rmse"]
     log("initial test rmse %.6f" % rmse0)
 
     it = 0
-    resident_fault = None
-    try:
-        job.run(hyper, 42, it, args.warmup, mode)
-        torch.cuda.synchronize()
-        # a resident launch that could not get the GPU to itself reports at the next call into the library: ask now
-        # (not with a loss pass: that would leave the caches in another state for the first timed launch)
-        from cu2rec_amd._lib import check
-        check(cu.lib().cu2rec_check_faults())
-    except cu.Cu2recError as e:
-        if "resident" not in str(e) or world > 1:
-            raise
-        # never silently: say so, and measure the one-launch-per-iteration kernel instead of nothing at all
-        resident_fault = str(e)
-        log("RESIDENT LAUNCH FAULT (%s) -- falling back to CU2REC_RESIDENT=0 for this run" % resident_fault)
-        cu.lib().cu2rec_hogwild_resident(0)
-        eng = Engine(train.rows, train.cols, f, train.global_bias, device=device)
-        job = ShardedSGD(eng, d_train, user_offset=user_offset, sync_every=sync_every, merge=args.merge, item_rates=rates)
-        job.run(hyper, 42, it, args.warmup, mode)
-        torch.cuda.synchronize()
+    job.run(hyper, 42, it, args.warmup, mode)
+    torch.cuda.synchronize()
+    check(L.cu2rec_check_faults())
     it += args.warmup
     log("warmup done")
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    job.run(hyper, 42, it, args.steps, mode)
-    job.finish_pending()  # an overlapped item-factor all-reduce still in flight belongs to the timed work
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    ev = HipEvents()
+    e0, e1 = ev.new(), ev.new()
+
+    def timed_region(start_it):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev.record(e0)
+        job.run(hyper, 42, start_it, args.steps, mode)
+        ev.record(e1)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, 1e-3 * ev.ms(e0, e1)
+
+    regions = []
+    first, first_dev = timed_region(it)
     it += args.steps
-    log("timed region: %d steps in %.4f s" % (args.steps, elapsed))
-    final = job.loss(d_test)  # the model after warmup + steps iterations, before the untimed extra passes below
-    final_iterations = it
+    regions.append((first, first_dev))
+    # a short region is mostly launch + synchronisation: repeat it and report the median (every region is exactly K steps)
+    n_regions = 1 if first >= 0.25 else 5
+    for _ in range(n_regions - 1):
+        regions.append(timed_region(it))
+        it += args.steps
+    check(L.cu2rec_check_faults())
+    elapsed = float(np.median([r[0] for r in regions]))
+    elapsed_dev = float(np.median([r[1] for r in regions]))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # ---- SGD kernel duration: HIP events around single launches on the launch stream (untimed extra pass).
-    # Hogwild calls of `sync_every` iterations are ONE resident launch when the user rows fit the register file
-    # (cu2rec_amd/csrc/resident.hip); otherwise a launch is one iteration (or --iters-per-launch of them).
-    import ctypes
-    blocks_c, upg_c = ctypes.c_int(0), ctypes.c_int(0)
-    resident = (args.mode == "hogwild" and args.iters_per_launch == 1 and
-                cu.lib().cu2rec_hogwild_resident_plan(train.rows, f, sync_every, ctypes.byref(blocks_c), ctypes.byref(upg_c)) == 1)
-    kernel_name = "sgd_resident_kernel" if resident else "sgd_%s_kernel" % args.mode
-    k_launch = sync_every if resident else (max(args.iters_per_launch, 1) if args.mode == "hogwild" else 1)
-    n_s = max(args.kernel_samples // (8 if resident else 1), 1)
-
-    def time_launches(n_samples, iters_per_launch, start_it):
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_samples)]
-        for a, b in evs:
-            a.record()
-            eng.sgd(d_train, hyper, 42, start_it, iters_per_launch, mode, True, user_offset)
-            b.record()
-            start_it += iters_per_launch
-        torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in evs]
-        return float(np.mean(ms)), float(np.min(ms)), start_it
-
-    kernel_ms, kernel_ms_min, it = time_launches(n_s, k_launch, it)
-    log("%s: %d iteration(s) per launch, avg %.2f us (min %.2f us) per launch" % (kernel_name, k_launch, 1e3 * kernel_ms,
-                                                                                   1e3 * kernel_ms_min))
-    # ---- the streaming form beside it (one launch per iteration, user rows through HBM): same data, same model
-    streaming = None
-    if resident:
-        prev = cu.lib().cu2rec_hogwild_resident(0)
-        try:
-            s_ms, s_min, it = time_launches(max(args.kernel_samples, 1), 1, it)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            eng.sgd(d_train, hyper, 42, it, 500, mode, True, user_offset)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-            it += 500
-        finally:
-            cu.lib().cu2rec_hogwild_resident(prev)
-        s_bytes = users_active * (16 * f + 32)
-        streaming = {"mode": "hogwild, one launch per iteration (CU2REC_RESIDENT=0): user rows stream through HBM",
-                     "kernel": "sgd_hogwild_kernel", "value": users_active * 500 / dt, "unit": "updates/s",
-                     "ms_per_step": 1e3 * dt / 500, "steps": 500, "kernel_avg_us": 1e3 * s_ms, "kernel_min_us": 1e3 * s_min,
-                     "algorithmic_bytes_per_launch": s_bytes, "achieved_GBs": s_bytes / (s_ms * 1e-3) / 1e9,
-                     "frac_of_hbm_peak": s_bytes / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        log("streaming kernel: avg %.2f us per launch, %.4f ms/step" % (1e3 * s_ms, streaming["ms_per_step"]))
-    # ---- the fused loss pass (train set), timed the same way: the other kernel of the path
-    le = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-    for a, b in le:
-        a.record()
-        eng.loss(d_train)
-        b.record()
-    torch.cuda.synchronize()
-    loss_ms = float(np.min([a.elapsed_time(b) for a, b in le]))
-    loss_hbm = 8 * train.nnz + 4 * f * (train.rows + train.cols) + 4 * (train.rows + train.cols) + 4 * (train.rows + 1)
-    loss_kernel = {"kernel": "loss_fused_kernel", "ratings": train.nnz, "ms": loss_ms,
-                   "ratings_per_s": train.nnz / (loss_ms * 1e-3),
-                   "bound": "L2 gather of item rows (nnz * 4f bytes) on top of the HBM stream",
-                   "algorithmic_hbm_bytes": loss_hbm, "hbm_GBs": loss_hbm / (loss_ms * 1e-3) / 1e9,
-                   "gather_bytes": 4 * f * train.nnz, "gather_GBs": 4 * f * train.nnz / (loss_ms * 1e-3) / 1e9,
-                   "note": "includes the 64 KB partial-sum copy back and host reduction (one call of cu2rec_loss)"}
-
-    # ---- the exact mode beside it: same data, fresh model, sequential semantics (bit-identical to the CPU oracle)
-    ordered = None
-    if world == 1 and args.ordered_steps > 0 and args.mode != "ordered":
-        eng_o = Engine(train.rows, train.cols, f, train.global_bias, device=device)
-        eng_o.sgd(d_train, hyper, 42, 0, 64, cu.SGD_ORDERED)  # warm-up incl. schedule workspace creation
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        eng_o.sgd(d_train, hyper, 42, 64, args.ordered_steps, cu.SGD_ORDERED)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        ordered = {"mode": "ordered (sequential semantics, deterministic; bit-identical to the CPU oracle in tests)",
-                   "value": users_active * args.ordered_steps / dt, "unit": "updates/s",
-                   "ms_per_step": 1e3 * dt / args.ordered_steps, "steps": args.ordered_steps,
-                   "test_rmse": eng_o.loss(d_test)["rmse"], "iterations_run": 64 + args.ordered_steps}
-        log("ordered mode: %.3f ms/step" % ordered["ms_per_step"])
-        del eng_o
-    # ---- opt-in Hogwild launch blocking beside it (4 updates per user per launch, user row in registers)
-    blocked = None
-    if world == 1 and args.mode == "hogwild" and args.iters_per_launch == 1 and args.ordered_steps > 0:
-        eng_b = Engine(train.rows, train.cols, f, train.global_bias, device=device)
-        cu.lib().cu2rec_hogwild_iters_per_launch(4)
-        try:
-            eng_b.sgd(d_train, hyper, 42, 0, 100, cu.SGD_HOGWILD)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            eng_b.sgd(d_train, hyper, 42, 100, 2000, cu.SGD_HOGWILD)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t1
-        finally:
-            cu.lib().cu2rec_hogwild_iters_per_launch(1)
-        blocked = {"mode": "hogwild, 4 iterations per launch (opt-in: users up to 3 iterations apart inside a launch)",
-                   "value": users_active * 2000 / dt, "unit": "updates/s", "ms_per_step": 1e3 * dt / 2000, "steps": 2000,
-                   "test_rmse": eng_b.loss(d_test)["rmse"], "iterations_run": 2100}
-        log("hogwild x4 per launch: %.4f ms/step" % blocked["ms_per_step"])
-        del eng_b
-    bytes_per_update = 16 * f + 32
-    alg_bytes = users_active * bytes_per_update * k_launch
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    total_users = users_active * world
-    if world > 1:
-        tu = torch.tensor([float(users_active)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(tu)
-        total_users = float(tu.item())
+    log("timed: %d region(s) of %d steps, median %.4f s (device %.4f s)" % (len(regions), args.steps, elapsed, elapsed_dev))
+    job.exchange()
+    final = job.loss(d_test)
+    final_iterations = it
+    exchanges = job.info()["exchanges"]
+    total_users = float(job.info()["users_total"])
     value = total_users * args.steps / elapsed
+    bytes_per_update = 16 * f + 32
+    alg_bytes = users_active * bytes_per_update * args.steps
+    achieved = alg_bytes / elapsed_dev / 1e9
+
+    side = {}
+    if world == 1 and not args.no_side_modes:
+        # ---- the sequential result at equal iterations: the exact ordered mode (bit-identical to the CPU oracle in tests)
+        def run_fresh(m, iters, policy=None):
+            mod = fresh_model()
+            prev = L.cu2rec_hogwild_resident(policy) if policy is not None else None
+            try:
+                mod.sgd(d_train, hyper, 42, 0, 64, mode=m)  # warm-up incl. workspace creation
+                torch.cuda.synchronize()
+                a, b = ev.new(), ev.new()
+                t1 = time.perf_counter()
+                ev.record(a)
+                done = 64
+                while done < iters:
+                    n = min(500, iters - done)
+                    mod.sgd(d_train, hyper, 42, done, n, mode=m)
+                    done += n
+                ev.record(b)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                dev = 1e-3 * ev.ms(a, b)
+            finally:
+                if prev is not None:
+                    L.cu2rec_hogwild_resident(prev)
+            check(L.cu2rec_check_faults())
+            return mod, (iters - 64) / dt * users_active, 1e3 * dt / (iters - 64), 1e3 * dev / (iters - 64)
+
+        gap_iters = final_iterations
+        seq, seq_rate, seq_ms, _ = run_fresh("ordered", gap_iters)
+        seq_rmse = seq.loss(d_test)["rmse"]
+        side["rmse_gap_vs_sequential"] = {
+            "iterations": gap_iters, "rmse": final["rmse"], "sequential_rmse": seq_rmse, "gap": abs(final["rmse"] - seq_rmse),
+            "tolerance": 1e-4, "sequential": "CU2REC_SGD_ORDERED: mf_sequential.cu:102-143's result (bit-identical to the CPU "
+                                             "oracle, tests/test_gpu_parity.py), same data, same sample stream, same iterations"}
+        side["ordered_mode"] = {"mode": "ordered (sequential semantics, exact)", "value": seq_rate, "unit": "updates/s",
+                                "ms_per_step": seq_ms, "test_rmse": seq_rmse, "iterations_run": gap_iters}
+        del seq
+        log("ordered mode: %.3f ms/step, gap of the timed mode %.2e" % (seq_ms, side["rmse_gap_vs_sequential"]["gap"]))
+        if mode == "blocksolve":
+            # ---- the racy modes beside it, with THEIR gap at the same iteration count
+            for name, policy, kernel in (("hogwild_resident_mode", 2, "sgd_resident_kernel"), ("hogwild_streaming_mode", 0, "sgd_hogwild_kernel")):
+                planned = L.cu2rec_hogwild_resident_plan(train.rows, f, 500, None, None) == 1
+                if policy == 2 and not planned:
+                    continue
+                hog, rate, ms, dev_ms = run_fresh("hogwild", gap_iters, policy)
+                r = hog.loss(d_test)["rmse"]
+                del hog
+                if policy == 2:  # user rows stay in registers: what must move per update is the item side only
+                    b_upd, peak, level = 8 * f + 16, GATHER_PEAK_GBS, "Infinity-Cache / fabric gather rate of random rows (MI355X_MICROARCH.md, Indexed rows)"
+                else:
+                    b_upd, peak, level = 16 * f + 32, HBM_PEAK_GBS, "HBM"
+                ach = users_active * b_upd / (dev_ms * 1e-3) / 1e9
+                side[name] = {"mode": "hogwild, %s" % ("ONE resident launch per 500 iterations (user rows in registers)" if policy == 2 else
+                                                       "one launch per iteration (user rows stream through HBM)"),
+                              "kernel": kernel, "value": rate, "unit": "updates/s", "ms_per_step": ms, "test_rmse": r,
+                              "iterations_run": gap_iters, "rmse_gap_vs_sequential": abs(r - seq_rmse),
+                              "meets_1e-4_tolerance": bool(abs(r - seq_rmse) <= 1e-4),
+                              "roofline": {"bytes_per_update": b_upd, "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
+                                           "bound": level, "device_ms_per_step": dev_ms}}
+                log("%s: %.4f ms/step, gap %.2e" % (name, ms, abs(r - seq_rmse)))
+        # ---- the fused loss pass (train set): the other kernel of the path
+        times = []
+        for _ in range(5):
+            a, b = ev.new(), ev.new()
+            ev.record(a)
+            model.loss(d_train)
+            ev.record(b)
+            times.append(ev.ms(a, b))
+        loss_ms = float(np.min(times))
+        loss_hbm = 8 * train.nnz + 4 * f * (train.rows + train.cols) + 4 * (train.rows + train.cols) + 4 * (train.rows + 1)
+        side["loss_kernel"] = {"kernel": "loss_fused_kernel", "ratings": train.nnz, "ms": loss_ms, "ratings_per_s": train.nnz / (loss_ms * 1e-3),
+                               "algorithmic_hbm_bytes": loss_hbm, "hbm_GBs": loss_hbm / (loss_ms * 1e-3) / 1e9,
+                               "frac_of_hbm_peak": loss_hbm / (loss_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "one call of cu2rec_loss, incl. the 64 KB partial-sum copy back and host reduction"}
 
     if rank == 0:
+        kernels = {"blocksolve": "one block-solve iteration = bs_gram_kernel + bs_solve_kernel + bs_update_kernel, sgd_ordered_kernel beside them "
+                                 "(per-kernel durations: profiles/r02_kernel_stats_blocksolve_*.csv)",
+                   "hogwild": "sgd_resident_kernel / sgd_hogwild_kernel", "ordered": "sgd_ordered_kernel", "serial": "sgd_serial_kernel"}
         line = {
             "metric": "ratings/sec (SGD updates/sec)", "value": value, "unit": "updates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s-shape synthetic ratings (users %d, items %d, train nnz %d, test nnz %d per GPU), "
-                                   "f=%d, lr .01, reg .02, mode %s%s" % (args.workload, train.rows, train.cols, train.nnz, test.nnz, f,
-                                                                           args.mode, "" if args.iters_per_launch == 1 else
-                                                                           " x%d iterations per launch" % args.iters_per_launch),
-                       "updates_per_step_per_gpu": users_active, "sync_every": sync_every if world > 1 else None,
-                       "merge": args.merge if world > 1 else None, "exchanges": job.exchanges},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s-shape synthetic ratings (users %d, items %d, train nnz %d, test nnz %d%s), f=%d, lr .01, reg .02, "
+                                   "mode %s" % (args.workload, full_train.rows, full_train.cols, full_train.nnz, full_test.nnz,
+                                                "" if world == 1 else (", users sharded over %d ranks" % world if args.scaling == "strong"
+                                                                       else " per GPU"), f, mode),
+                       "mode": mode, "updates_per_step": total_users, "updates_per_step_this_rank": users_active,
+                       "sync_every": info["sync_every"] if world > 1 else None, "merge": args.merge if world > 1 else None,
+                       "exchanges": exchanges, "wire_bytes_per_exchange": info["wire_bytes"] if world > 1 else None},
+            "timed_region_s": elapsed, "timed_regions": [round(r[0], 6) for r in regions],
             "test_rmse": final["rmse"], "test_rmse_initial": rmse0, "iterations_run": final_iterations,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": kernel_name, "kernel_avg_us": 1e3 * kernel_ms,
-                         "kernel_min_us": 1e3 * kernel_ms_min, "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_update": bytes_per_update, "iterations_per_launch": k_launch},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "traffic_from_profile": "profiles/ (rocprofv3 --pmc passes, fabric-side counters)",
+                         "kernel": kernels[mode], "bytes_per_update": bytes_per_update,
+                         "algorithmic_bytes": alg_bytes, "device_seconds": elapsed_dev,
+                         "note": "algorithmic bytes of the timed region (rank 0's updates x (16 f + 32)) / its duration by HIP events on "
+                                 "the launch stream; the mode's sequential chains are latency bound, not bandwidth bound: DESIGN.md section 4"},
         }
-        if resident_fault:
-            line["resident_fault"] = resident_fault
-        if resident:
-            line["roofline"]["note"] = (
-                "one persistent launch = %d iterations; %d workgroups x 32 groups keep %d user rows each in registers, so "
-                "the 8f bytes per update of user-row traffic in the algorithmic count never reach HBM: frac > 1 means the "
-                "kernel beats the roofline of the streaming formulation, `traffic` is what HBM really moved"
-                % (k_launch, blocks_c.value, upg_c.value))
-        traffic = measured_traffic(args.workload, f, kernel_name)
-        if traffic:
-            line["roofline"]["traffic"] = traffic["bytes_per_launch"]
-            line["roofline"]["traffic_source"] = traffic["source"]
-        line["loss_kernel"] = loss_kernel
-        if streaming:
-            line["hogwild_streaming_mode"] = streaming
-        if ordered:
-            line["ordered_mode"] = ordered
-        if blocked:
-            line["hogwild_blocked_mode"] = blocked
+        line.update(side)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(train, test, f, hyper)
         print(json.dumps(line), flush=True)
+    job.close()
+    comm.close()
     if world > 1:
         dist.destroy_process_group()
 

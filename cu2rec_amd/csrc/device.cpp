@@ -357,8 +357,10 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
     }
     other_in_sync = false;  // another mode moves Q on without the second pair
     if (mode == CU2REC_SGD_ORDERED || mode == CU2REC_SGD_BLOCKSOLVE) {
-        if (!train.schedule)
+        if (!train.schedule) {
             train.schedule.reset(new OrderedSchedule(train.indptr.ptr, train.indices.ptr, train.rows, cols, train.nnz));
+            train.schedule->speculate = true;  // the schedule is destroyed with the arrays it reads
+        }
         sgd_update_ordered(*train.schedule, train.indptr.ptr, train.indices.ptr, train.data.ptr, train.rows, cols, P.ptr,
                            ld, Q.ptr, ldq, user_bias.ptr, item_bias.ptr, global_bias, n_factors, h, seed, iter0, n_iters,
                            update_items, user_offset, stream, mode == CU2REC_SGD_BLOCKSOLVE);

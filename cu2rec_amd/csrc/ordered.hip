@@ -623,16 +623,14 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         const uint64_t *sv;
     } ready[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     const int n_batches = (n_iters + max_batch - 1) / max_batch;
-    auto schedule = [&](int j) {
-        const int slot = j & 1, first = j * max_batch;
-        const int nb = std::min(max_batch, n_iters - first);
+    auto schedule = [&](int slot, uint64_t first_iter, int nb) {
         const int b_bits = bits_for(nb);
         const uint32_t sentinel = 1u << (item_bits + b_bits);
         const size_t n = static_cast<size_t>(nb) * n_rows;
         const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 1 << 16));
         if (slot_used[slot]) CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[slot], 0));  // its last batch has been run
         hipLaunchKernelGGL(schedule_keys_kernel, dim3(blocks), dim3(kBlock), 0, sched, a.indptr, a.indices, a.data,
-                           item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, iter0 + first, a.user_offset,
+                           item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, first_iter, a.user_offset,
                            keys[slot][0].ptr, vals[slot][0].ptr);
         CU2REC_HIP(hipGetLastError());
         hipcub::DoubleBuffer<uint32_t> dk(keys[slot][0].ptr, keys[slot][1].ptr);
@@ -647,16 +645,34 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
         slot_used[slot] = true;
     };
-    // the CSR / model pointers the schedule reads must be final: whatever the caller queued on `stream` so far
-    CU2REC_HIP(hipEventRecord(ev_consumed[1], stream));
-    CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[1], 0));
-    slot_used[1] = true;  // (that record also stands for "slot 1 free": nothing of it is queued behind this point)
-    schedule(0);
+    // A call usually continues where the last one stopped, with as many iterations (cu2rec_train's segments, a bench's
+    // steps): the last call scheduled that batch speculatively.  If this is it, its first batch is already sorted.
+    const int nb_first = std::min(max_batch, n_iters);
+    int base_slot = 0;
+    const bool hit = spec.valid && spec.seed == a.seed && spec.iter0 == iter0 && spec.nb == nb_first &&
+                     spec.user_offset == a.user_offset && spec.indptr == a.indptr && spec.blocksolve == blocksolve;
+    if (hit) {
+        base_slot = spec.slot;
+        ready[base_slot] = Scheduled{spec.sk, spec.sv};
+    } else {
+        // the CSR / model pointers the schedule reads must be final: whatever the caller queued on `stream` so far
+        CU2REC_HIP(hipEventRecord(ev_consumed[1], stream));
+        CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[1], 0));
+        slot_used[1] = true;  // (that record also stands for "slot 1 free": nothing of it is queued behind this point)
+        schedule(0, iter0, nb_first);
+    }
+    spec.valid = false;
     int done = 0;
     for (int j = 0; j < n_batches; ++j) {
-        const int slot = j & 1;
+        const int slot = (base_slot + j) & 1;
         const int nb = std::min(max_batch, n_iters - done);
-        if (j + 1 < n_batches) schedule(j + 1);  // runs beside this batch's iterations
+        if (j + 1 < n_batches) {
+            schedule(slot ^ 1, iter0 + done + nb, std::min(max_batch, n_iters - done - nb));  // beside this batch's iterations
+        } else if (speculate) {  // for the next call: it starts at iter0 + n_iters and is as long as this one
+            schedule(slot ^ 1, iter0 + n_iters, nb_first);
+            spec = Speculated{true, a.seed, iter0 + static_cast<uint64_t>(n_iters), nb_first, a.user_offset, a.indptr, blocksolve,
+                              slot ^ 1, ready[slot ^ 1].sk, ready[slot ^ 1].sv};
+        }
         CU2REC_HIP(hipStreamWaitEvent(stream, ev_ready[slot], 0));
         const uint32_t *sk = ready[slot].sk;
         const uint64_t *sv = ready[slot].sv;

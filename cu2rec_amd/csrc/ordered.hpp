@@ -33,6 +33,19 @@ struct OrderedSchedule {
     hipStream_t sched = nullptr;
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     bool slot_used[2] = {false, false};
+    // Schedule the next call's first batch ahead (it reads the CSR arrays after run() has returned): only where the
+    // schedule lives and dies with the CSR it reads, i.e. the owned-object layer (cu2rec_csr); off for raw pointers.
+    bool speculate = false;
+    struct Speculated {  // the batch scheduled ahead for the NEXT call (see run())
+        bool valid = false;
+        uint64_t seed = 0, iter0 = 0;
+        int nb = 0, user_offset = 0;
+        const int *indptr = nullptr;
+        bool blocksolve = false;
+        int slot = 0;
+        const uint32_t *sk = nullptr;
+        const uint64_t *sv = nullptr;
+    } spec;
     DeviceBuffer<unsigned char> temp;
     size_t temp_bytes = 0;
     // block-solve mode: items are ranked by their expected updates per iteration (sum over raters of 1 / degree);
