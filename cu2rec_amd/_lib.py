@@ -112,6 +112,9 @@ SIGNATURES = {
     "cu2rec_model_destroy": (None, [_P]),
     "cu2rec_model_sgd": (C.c_int, [_P, _P, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "cu2rec_model_loss": (C.c_int, [_P, _P, _dp, _dp, _fp, _fp]),
+    "cu2rec_model_scores": (C.c_int, [_P, _P, _P]),
+    "cu2rec_model_scores_host": (C.c_int, [_P, _P]),
+    "cu2rec_model_recommend": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "cu2rec_train": (C.c_int, [_P, _P, C.POINTER(Config), _P, C.c_int, C.c_int, _P, C.POINTER(TrainStats)]),
     "cu2rec_shard_plan": (C.c_int, [C.c_int, C.c_int, _P]),
     "cu2rec_comm_unique_id": (C.c_int, [_P]),

@@ -261,6 +261,19 @@ class Model:
         check(lib().cu2rec_model_download(self._h, _ptr(P), _ptr(Q), _ptr(ub), _ptr(ib)))
         return P, Q, ub, ib
 
+    def scores(self):
+        """predict_ratings (predict.cu:17-30) for every user against every item -> (rows, cols) float32."""
+        out = np.empty((self.rows, self.cols), np.float32)
+        check(lib().cu2rec_model_scores_host(self._h, _ptr(out)))
+        return out
+
+    def recommend(self, rated, k):
+        """get_recommendations (predict.cu:49-65) for every user: the k best unrated items -> (items, scores), each
+        (rows, k); -1 / NaN where a user has fewer than k unrated items.  rated: DeviceCSR (row u = user u) or None."""
+        items, scores = np.empty((self.rows, k), np.int32), np.empty((self.rows, k), np.float32)
+        check(lib().cu2rec_model_recommend(self._h, rated._h if rated is not None else None, int(k), _ptr(items), _ptr(scores)))
+        return items, scores
+
     def device_ptrs(self):
         a, b, c, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(lib().cu2rec_model_device_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))

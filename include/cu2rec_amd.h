@@ -330,6 +330,20 @@ int cu2rec_model_loss(const cu2rec_model *m, const cu2rec_csr *ratings, double *
                       float *mae, float *rmse);
 
 /* ------------------------------------------------------------------------------------------
+ * Scoring and ranking for MANY users at once -- replaces predict_ratings (predict.cu:17-30) and get_recommendations
+ * (predict.cu:49-65), which the reference runs on the host for its one user.
+ * scores[u * cols + i] = ((gb + ub[u]) + ib[i]) + p_u . q_i for every user of the model and every item: one dense
+ * product on the matrix cores (f32 in, f32 accumulate).  The sum over the factors is associated differently from the
+ * reference's sequential loop: equal up to float rounding.
+ * ---------------------------------------------------------------------------------------- */
+int cu2rec_model_scores(const cu2rec_model *m, float *scores_device /* rows * cols floats */, void *stream);
+int cu2rec_model_scores_host(const cu2rec_model *m, float *scores_host /* rows * cols floats */);
+/* For every user the k best items it has NOT rated, best predicted rating first.  rated: a CSR whose row u holds user
+ * u's ratings (NULL: nothing is excluded).  items_out / scores_out: host arrays of rows * k entries; a user with fewer
+ * than k unrated items gets -1 / NaN padding. */
+int cu2rec_model_recommend(const cu2rec_model *m, const cu2rec_csr *rated, int k, int *items_out, float *scores_out);
+
+/* ------------------------------------------------------------------------------------------
  * train() -- replaces both overloads of train (training.h:12-15, training.cu:21-217):
  * total_iterations iterations; loss on train and test when i == 0, (i+1) % check_error == 0
  * or last (training.cu:118) printed as "TRAIN: Iteration %d GPU MAE: %f RMSE: %f" / "TEST: ..."
