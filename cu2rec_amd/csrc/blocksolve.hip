@@ -57,8 +57,6 @@ __device__ __forceinline__ float lane_value(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-__device__ __forceinline__ int lane_value(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-
 // row of the 32x32 accumulator tile held in register `reg` of a lane of half h (column = lane & 31)
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
@@ -171,120 +169,140 @@ __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict
 }
 
 // ---- phase 1: the inverse factor of every block --------------------------------------------------------------------
-// One wavefront per block.  The 64 user rows are gathered with coalesced 128-byte pieces into LDS (odd row stride: a
-// column read is conflict free).  Lane (k = l & 31, h = l >> 5) takes half h of rows k and 32 + k;
-// v_mfma_f32_32x32x2_f32 wants A[i = l & 31][kk = l >> 5] and B[kk = l >> 5][j = l & 31], so for the two diagonal tiles
-// (B = A^T) the SAME register is both operands, and the contraction index pairs column c of half 0 with column c of
-// half 1.  With N = lr L in tiles [[N00, 0], [N10, N11]] (strictly lower triangular diagonal tiles):
+// One workgroup of four wavefronts per block.  The 64 user rows are gathered with coalesced 128-byte pieces into LDS
+// (odd row stride: a column read is conflict free), 16 rows per wavefront, all of a lane's loads in flight together.
+// v_mfma_f32_32x32x2_f32 wants A[i = l & 31][kk = l >> 5] and B[kk = l >> 5][j = l & 31]: lane (k = l & 31, h = l >> 5)
+// feeds half h of the columns of row k, so for the two diagonal tiles (B = A^T) the SAME register is both operands.
+// The three Gram tiles are three wavefronts' work (one matrix pipe each).  With N = lr L in tiles [[N00, 0], [N10, N11]]
+// (strictly lower triangular diagonal tiles):
 //     M = (I + N)^-1 = [[M11, 0], [M21, M22]],  M11 = (I + N00)^-1,  M22 = (I + N11)^-1,  M21 = -M22 N10 M11.
-// The two triangular inversions run side by side in the two lane halves (lane = column, forward substitution with the
-// N entries broadcast from LDS); the two products for M21 are matrix-core work again, the first one's accumulator tile
-// being the second one's B operand as it stands.
-__global__ __launch_bounds__(64) void bs_gram_kernel(SgdArgs a, BsIteration it) {
+// The two triangular inversions run side by side in the two lane halves of wavefront 0 (lane = column, forward
+// substitution with the N rows broadcast from LDS one row ahead of their use, four partial sums per row); the two
+// products for M21 are matrix-core work again, the first one's accumulator tile being the second one's B operand as it
+// stands.
+constexpr int kGramTabFloats = 2 * kB;  // a^d | c^d, d in [0, 64)
+__device__ __forceinline__ size_t gram_tile_float4s(int nslots) { return static_cast<size_t>(kB) * (nslots | 1); }
+
+__global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it) {
     extern __shared__ float4 bs_smem[];
-    const int lane = threadIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x;
     WaveStamp stamp(it);
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) return;
     const int nslots = a.nslots, RS = nslots | 1;
-    float4 *tile = bs_smem;  // [kB][RS]; reused for the N / M tiles once the Gram products are done
+    float4 *tile = bs_smem;  // [kB][RS]
+    float *Ns = reinterpret_cast<float *>(bs_smem + gram_tile_float4s(nslots));  // N00 | N11 | N10
+    float *Ms = Ns + 3 * kH * kMS;                                                // M11 | M22
+    float *tab = Ms + 2 * kH * kMS;
     const bool mine = lane < bd.n_valid;  // lane l: link l
     const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
     const int x = static_cast<int>(val >> 32);
-    if (mine)  // what the link's error starts from: r - gb - ub (mf_sequential.cu:119-126 without b and p.q)
-        it.base[bd.pos0 + lane] = (__uint_as_float(static_cast<uint32_t>(val)) - a.global_bias) - a.user_bias[x];
+    if (wave == 3) {
+        if (mine)  // what the link's error starts from: r - gb - ub (mf_sequential.cu:119-126 without b and p.q)
+            it.base[bd.pos0 + lane] = (__uint_as_float(static_cast<uint32_t>(val)) - a.global_bias) - a.user_bias[x];
+        tab[lane] = it.tables[kTabApow + lane];
+        tab[kB + lane] = it.tables[kTabCpow + lane];
+    }
     stamp.mark(it, 0);
-    // gather: 8 lanes x 16 bytes per row piece, 8 rows per pass.  Every load is unconditional at a clamped address and
-    // zeroed afterwards: a predicated load makes the compiler branch around it and wait for each one separately.
+    // gather: 8 lanes x 16 bytes per row piece, 8 rows per pass, this wavefront's 16 rows.  Every load is unconditional at
+    // a clamped address: a predicated load makes the compiler branch around it and wait for each one separately.
     const int rsub = lane >> 3, cs = lane & 7;
     const int nch = (nslots + 7) >> 3;
-    for (int c0 = 0; c0 < nch; c0 += 2) {
+    for (int c0 = 0; c0 < nch; c0 += 4) {
+        float4 v[2][4];
 #pragma unroll
-        for (int p0 = 0; p0 < 8; p0 += 2) {
-            float4 v[2][2];
+        for (int pp = 0; pp < 2; ++pp) {
+            const int xr = __shfl(x, 16 * wave + 8 * pp + rsub);
+            const float4 *src = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(xr) * a.ldp);
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int xr = __shfl(x, 8 * (p0 + pp) + rsub);
-                const float4 *src = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(xr) * a.ldp);
+            for (int c = 0; c < 4; ++c) v[pp][c] = src[min(8 * (c0 + c) + cs, nslots - 1)];
+        }
 #pragma unroll
-                for (int c = 0; c < 2; ++c) v[pp][c] = src[min(8 * (c0 + c) + cs, nslots - 1)];
-            }
+        for (int pp = 0; pp < 2; ++pp) {
+            const int row = 16 * wave + 8 * pp + rsub;
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
-                const int row = 8 * (p0 + pp) + rsub;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int slot = 8 * (c0 + c) + cs;
-                    if (slot < nslots) tile[row * RS + slot] = row < bd.n_valid ? v[pp][c] : zero4();
-                }
+            for (int c = 0; c < 4; ++c) {
+                const int slot = 8 * (c0 + c) + cs;
+                if (slot < nslots) tile[row * RS + slot] = row < bd.n_valid ? v[pp][c] : zero4();
             }
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     stamp.mark(it, 1);
     const int k = lane & 31, h = lane >> 5;
-    const int S0 = (nslots + 1) >> 1;  // slots per lane half
-    f32x16 g00, g11, g10;
+    if (wave < 3) {  // 0: G00 -> N00, 1: G11 -> N11, 2: G10 -> N10 (rows: links 32.., columns: links 0..31)
+        const int S0 = (nslots + 1) >> 1;  // slots per lane half
+        const float4 *ra = tile + (wave == 0 ? k : kH + k) * RS, *rb = tile + (wave == 1 ? kH + k : k) * RS;
+        f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) g00[i] = g11[i] = g10[i] = 0.f;
-    for (int c = 0; c < S0; c += 2) {
-        float4 v0[2], v1[2];
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int c = 0; c < S0; c += 2) {
+            float4 va[2], vb[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int slot = h * S0 + c + i;
-            const bool ok = c + i < S0 && slot < nslots;
-            const float4 t0 = tile[k * RS + min(slot, nslots - 1)], t1 = tile[(kH + k) * RS + min(slot, nslots - 1)];
-            v0[i] = ok ? t0 : zero4();
-            v1[i] = ok ? t1 : zero4();
+            for (int i = 0; i < 2; ++i) {
+                const int slot = h * S0 + c + i;
+                const bool ok = c + i < S0 && slot < nslots;
+                const float4 t0 = ra[min(slot, nslots - 1)], t1 = rb[min(slot, nslots - 1)];
+                va[i] = ok ? t0 : zero4();
+                vb[i] = ok ? t1 : zero4();
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float pa[4] = {va[i].x, va[i].y, va[i].z, va[i].w}, pb[4] = {vb[i].x, vb[i].y, vb[i].z, vb[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[e], pb[e], acc, 0, 0, 0);
+            }
         }
+        const float lr = a.h.lr;
+        auto entry = [&](int d, float gram) { return lr * (tab[kB + d] + tab[d] * gram); };
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float p0[4] = {v0[i].x, v0[i].y, v0[i].z, v0[i].w}, p1[4] = {v1[i].x, v1[i].y, v1[i].z, v1[i].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                g00 = __builtin_amdgcn_mfma_f32_32x32x2f32(p0[e], p0[e], g00, 0, 0, 0);
-                g11 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], p1[e], g11, 0, 0, 0);
-                g10 = __builtin_amdgcn_mfma_f32_32x32x2f32(p1[e], p0[e], g10, 0, 0, 0);  // rows: links 32.., columns: links 0..31
+        for (int reg = 0; reg < 16; ++reg) {
+            const int j = acc_row(reg, h);
+            if (wave < 2) {
+                // a diagonal tile is symmetric: read the lane as the link k and the register's row as j
+                const int d = max(k - 1 - j, 0);
+                Ns[(wave * kH + k) * kMS + j] = j < k && wave * kH + k < bd.n_valid ? entry(d, acc[reg]) : 0.f;
+            } else {
+                // the off-diagonal tile: register row r = link 32 + r, lane column = link k
+                Ns[(2 * kH + j) * kMS + k] = kH + j < bd.n_valid ? entry(kH + j - 1 - k, acc[reg]) : 0.f;
             }
         }
     }
+    __syncthreads();
     stamp.mark(it, 2);
-    __builtin_amdgcn_wave_barrier();  // the tile is dead from here on: its LDS becomes N00 | N11 | N10 | M11 | M22
-    float *Ns = reinterpret_cast<float *>(bs_smem);
-    float *Ms = Ns + 3 * kH * kMS;
-    const float lr = a.h.lr;
-    auto entry = [&](int d, float gram) { return lr * (exp2f(static_cast<float>(d) * it.log2c) + exp2f(static_cast<float>(d) * it.log2a) * gram); };
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int j = acc_row(reg, h);
-        // the diagonal tiles are symmetric: read the lane as the link k and the register's row as j
-        const bool low = j < k;
-        const float n00 = low && k < bd.n_valid ? entry(k - 1 - j, g00[reg]) : 0.f;
-        const float n11 = low && kH + k < bd.n_valid ? entry(k - 1 - j, g11[reg]) : 0.f;
-        Ns[k * kMS + j] = n00;
-        Ns[(kH + k) * kMS + j] = n11;
-        // the off-diagonal tile: register row r = link 32 + r, lane column = link k
-        const int r = j;
-        Ns[(2 * kH + r) * kMS + k] = kH + r < bd.n_valid ? entry(kH + r - 1 - k, g10[reg]) : 0.f;
+    if (wave != 0) {
+        stamp.done(it, 1, 4 * g + wave);
+        return;
     }
-    __builtin_amdgcn_wave_barrier();
     // M11 (lanes 0-31) and M22 (lanes 32-63): lane = column, m[kk] = M[kk][column]
     float m[kH];
     {
         const float *Nh = Ns + h * kH * kMS;
+        float4 cur[8], nxt[8];
+        m[0] = k == 0 ? 1.f : 0.f;
+        cur[0] = *reinterpret_cast<const float4 *>(Nh + kMS);
 #pragma unroll
-        for (int kk = 0; kk < kH; ++kk) {
-            float s = kk == k ? 1.f : 0.f;
+        for (int kk = 1; kk < kH; ++kk) {
+            if (kk + 1 < kH) {
+#pragma unroll
+                for (int i4 = 0; i4 < (kk + 4) / 4; ++i4) nxt[i4] = *reinterpret_cast<const float4 *>(Nh + (kk + 1) * kMS + 4 * i4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float s[4] = {kk == k ? 1.f : 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i4 = 0; i4 < (kk + 3) / 4; ++i4) {
-                const float4 n4 = *reinterpret_cast<const float4 *>(Nh + kk * kMS + 4 * i4);
-                if (4 * i4 + 0 < kk) s = __builtin_fmaf(-n4.x, m[4 * i4 + 0], s);
-                if (4 * i4 + 1 < kk) s = __builtin_fmaf(-n4.y, m[4 * i4 + 1], s);
-                if (4 * i4 + 2 < kk) s = __builtin_fmaf(-n4.z, m[4 * i4 + 2], s);
-                if (4 * i4 + 3 < kk) s = __builtin_fmaf(-n4.w, m[4 * i4 + 3], s);
+                const float nv[4] = {cur[i4].x, cur[i4].y, cur[i4].z, cur[i4].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * i4 + e < kk) s[e] = __builtin_fmaf(-nv[e], m[4 * i4 + e], s[e]);
             }
-            m[kk] = s;
+            m[kk] = (s[0] + s[1]) + (s[2] + s[3]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < kH) {
+#pragma unroll
+                for (int i4 = 0; i4 < (kk + 4) / 4; ++i4) cur[i4] = nxt[i4];
+            }
         }
     }
     float *Mg = it.Mbuf + static_cast<size_t>(g) * kBsFactorFloats;
@@ -321,7 +339,7 @@ __global__ __launch_bounds__(64) void bs_gram_kernel(SgdArgs a, BsIteration it) 
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) Mg[kH * kH + acc_row(reg, h) * kH + k] = -macc[reg];
     stamp.mark(it, 3);
-    stamp.done(it, 1, g);
+    stamp.done(it, 1, 4 * g);
 }
 
 // ---- phase 2: the chains ----------------------------------------------------------------------------------------------
@@ -624,56 +642,77 @@ __global__ __launch_bounds__(256) void bs_solve_kernel(SgdArgs a, BsIteration it
 // ---- phase 3: the user side of every hot block ---------------------------------------------------------------------
 // One wavefront per (block, 32 columns).  T[k][j] = lr a^(k-1-j) e_j (j < k), 64 x 64 lower triangular in three 32 x 32
 // tiles, is the A operand, the block's user rows the B operand, the accumulators start from a^k q0: the result is the
-// item row as link k saw it.
+// item row as link k saw it.  The 64 x 32 piece of P comes in with eight 16-byte loads per lane into LDS, is both the B
+// operand and the old value of the update, takes the new values and leaves with eight 16-byte stores per lane; errors,
+// user ids and the powers of a are read from LDS as well (a lane-dependent readlane would turn into branches).
+constexpr int kUpdStride = 36;                               // floats per tile row: 16-byte rows, 2-way conflicts at most
+constexpr int kUpdWaveFloats = kB * kUpdStride + 2 * kB;     // tile | e | user ids
+constexpr int kUpdPowPad = 32;                               // a^d, d in [-32, 64), zero below 0
 __global__ __launch_bounds__(256) void bs_update_kernel(SgdArgs a, BsIteration it, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float upd_smem[4 * kUpdWaveFloats + kUpdPowPad + kB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *pw = upd_smem + 4 * kUpdWaveFloats;
+    if (threadIdx.x < kUpdPowPad + kB)
+        pw[threadIdx.x] = threadIdx.x < kUpdPowPad ? 0.f : it.tables[kTabApow + threadIdx.x - kUpdPowPad];
+    __syncthreads();
     const int unit = blockIdx.x * 4 + wave;
     const int g = unit / ntiles, ct = unit - g * ntiles;
     if (g >= it.max_blocks) return;
     WaveStamp stamp(it);
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) return;
+    float *tile = upd_smem + wave * kUpdWaveFloats;
+    float *se = tile + kB * kUpdStride;
+    int *sx = reinterpret_cast<int *>(se + kB);
     const int c = lane & 31, h = lane >> 5;
     const bool mine = lane < bd.n_valid;  // lane l: link l
+    // links past the end of a short block: the last link's row (finite, loaded, never stored) with e = 0
     const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
-    const int x = mine ? static_cast<int>(val >> 32) : -1;
+    const int x = static_cast<int>(val >> 32);
     const float e_all = it.ebuf[bd.pos0 + min(lane, bd.n_valid - 1)];
     const float e = mine ? e_all : 0.f;
+    se[lane] = e;
+    sx[lane] = x;
     const float lr = a.h.lr;
     const int ncols = 4 * a.nslots;
     const int col = 32 * ct + c, colc = min(col, ncols - 1);
-    const bool colok = col < ncols;
+    const float qs = it.qstart[static_cast<size_t>(g) * a.ldq + colc];
+    __builtin_amdgcn_wave_barrier();
+    const int rsub = lane >> 3, cs = lane & 7;
+    const int slot = 8 * ct + cs, slotc = min(slot, a.nslots - 1);
+    {
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[i] = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(sx[8 * i + rsub]) * a.ldp)[slotc];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(tile + (8 * i + rsub) * kUpdStride + 4 * cs) = v[i];
+    }
+    __builtin_amdgcn_wave_barrier();
     // operands of step s: the contraction index is 16 h + s inside a 32-link half
     float t00[16], t10[16], t11[16], b0[16], b1[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        const int j = 16 * h + s;
-        const float e0 = h ? lane_value(e, 16 + s) : lane_value(e, s);
-        const float e1 = h ? lane_value(e, 48 + s) : lane_value(e, 32 + s);
-        const int x0 = h ? lane_value(x, 16 + s) : lane_value(x, s);
-        const int x1 = h ? lane_value(x, 48 + s) : lane_value(x, 32 + s);
-        const float near = lr * exp2f(static_cast<float>(max(c - 1 - j, 0)) * it.log2a);  // a^(k-1-j) inside a diagonal tile
-        t00[s] = j < c ? near * e0 : 0.f;                                                  // row k = c
-        t11[s] = j < c ? near * e1 : 0.f;                                                  // row 32 + c, column 32 + j
-        t10[s] = lr * exp2f(static_cast<float>(kH + c - 1 - j) * it.log2a) * e0;          // row 32 + c, column j
-        const float p0 = a.P[static_cast<size_t>(max(x0, 0)) * a.ldp + colc];              // unconditional, see bs_gram_kernel
-        const float p1 = a.P[static_cast<size_t>(max(x1, 0)) * a.ldp + colc];
-        b0[s] = x0 >= 0 && colok ? p0 : 0.f;
-        b1[s] = x1 >= 0 && colok ? p1 : 0.f;
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 e0 = *reinterpret_cast<const float4 *>(se + 16 * h + 4 * s4);
+        const float4 e1 = *reinterpret_cast<const float4 *>(se + kH + 16 * h + 4 * s4);
+        const float e0v[4] = {e0.x, e0.y, e0.z, e0.w}, e1v[4] = {e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = 4 * s4 + i, j = 16 * h + s;
+            const float near = lr * pw[kUpdPowPad + c - 1 - j];      // a^(k-1-j) inside a diagonal tile, 0 for j >= k
+            t00[s] = near * e0v[i];                                  // row k = c
+            t11[s] = near * e1v[i];                                  // row 32 + c, column 32 + j
+            t10[s] = lr * pw[kUpdPowPad + kH + c - 1 - j] * e0v[i];  // row 32 + c, column j
+            b0[s] = tile[j * kUpdStride + c];
+            b1[s] = tile[(kH + j) * kUpdStride + c];
+        }
     }
-    const float qs_all = it.qstart[static_cast<size_t>(g) * a.ldq + colc];
-    const float qs = colok ? qs_all : 0.f;
     f32x16 acc0, acc1;
-    float pold0[16], pold1[16];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int kk = acc_row(reg, h), kk0 = acc_row(reg, 0);
-        acc0[reg] = qs * exp2f(static_cast<float>(kk) * it.log2a);
-        acc1[reg] = qs * exp2f(static_cast<float>(kH + kk) * it.log2a);
-        const int xa = h ? lane_value(x, kk0 + 4) : lane_value(x, kk0);
-        const int xb = h ? lane_value(x, kH + kk0 + 4) : lane_value(x, kH + kk0);
-        pold0[reg] = a.P[static_cast<size_t>(max(xa, 0)) * a.ldp + colc];
-        pold1[reg] = a.P[static_cast<size_t>(max(xb, 0)) * a.ldp + colc];
+        const int kk = acc_row(reg, h);
+        acc0[reg] = qs * pw[kUpdPowPad + kk];
+        acc1[reg] = qs * pw[kUpdPowPad + kH + kk];
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -682,17 +721,30 @@ __global__ __launch_bounds__(256) void bs_update_kernel(SgdArgs a, BsIteration i
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(t11[s], b1[s], acc1, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();  // every B operand has been read: the tile takes the new values
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int kk0 = acc_row(reg, 0);
-        const int xa = h ? lane_value(x, kk0 + 4) : lane_value(x, kk0);
-        const int xb = h ? lane_value(x, kH + kk0 + 4) : lane_value(x, kH + kk0);
-        const float ea = h ? lane_value(e, kk0 + 4) : lane_value(e, kk0);
-        const float eb = h ? lane_value(e, kH + kk0 + 4) : lane_value(e, kH + kk0);
-        if (xa >= 0 && colok)  // mf_sequential.cu:133-134
-            a.P[static_cast<size_t>(xa) * a.ldp + col] = pold0[reg] + lr * (ea * acc0[reg] - a.h.p_reg * pold0[reg]);
-        if (xb >= 0 && colok)
-            a.P[static_cast<size_t>(xb) * a.ldp + col] = pold1[reg] + lr * (eb * acc1[reg] - a.h.p_reg * pold1[reg]);
+    for (int t = 0; t < 4; ++t) {
+        const float4 ea = *reinterpret_cast<const float4 *>(se + 8 * t + 4 * h);
+        const float4 eb = *reinterpret_cast<const float4 *>(se + kH + 8 * t + 4 * h);
+        const float eav[4] = {ea.x, ea.y, ea.z, ea.w}, ebv[4] = {eb.x, eb.y, eb.z, eb.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int reg = 4 * t + i, kk = acc_row(reg, h);
+            float *p0 = tile + kk * kUpdStride + c, *p1 = tile + (kH + kk) * kUpdStride + c;
+            const float o0 = *p0, o1 = *p1;
+            *p0 = o0 + lr * (eav[i] * acc0[reg] - a.h.p_reg * o0);  // mf_sequential.cu:133-134
+            *p1 = o1 + lr * (ebv[i] * acc1[reg] - a.h.p_reg * o1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (slot < a.nslots) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * i + rsub;
+            if (row < bd.n_valid)
+                reinterpret_cast<float4 *>(a.P + static_cast<size_t>(sx[row]) * a.ldp)[slot] =
+                    *reinterpret_cast<const float4 *>(tile + row * kUpdStride + 4 * cs);
+        }
     }
     if (ct == 0 && mine) {
         const float ub = a.user_bias[x];
@@ -749,14 +801,14 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
-    const size_t gram_lds = std::max(static_cast<size_t>(kB) * (a.nslots | 1) * 16, static_cast<size_t>(5) * kH * kMS * 4);
+    const size_t gram_lds = static_cast<size_t>(kB) * (a.nslots | 1) * 16 + (static_cast<size_t>(5) * kH * kMS + kGramTabFloats) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bs_gram_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(64), gram_lds, stream, a, it);
+    hipLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), gram_lds, stream, a, it);
     CU2REC_HIP(hipGetLastError());
 }
 

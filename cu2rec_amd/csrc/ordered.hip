@@ -572,8 +572,8 @@ std::atomic<float> g_bs_min_rate{-1.f};
 
 float blocksolve_min_rate(float rate) {
     float prev = g_bs_min_rate.load();
-    if (prev < 0.f) {  // first use: default 160 expected updates per iteration, CU2REC_BLOCKSOLVE_RATE overrides
-        float init = 160.f;
+    if (prev < 0.f) {  // first use: default 320 expected updates per iteration, CU2REC_BLOCKSOLVE_RATE overrides
+        float init = 320.f;
         if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_RATE")) init = std::max(0.01f, static_cast<float>(std::atof(env)));
         g_bs_min_rate.compare_exchange_strong(prev, init);
         prev = g_bs_min_rate.load();
