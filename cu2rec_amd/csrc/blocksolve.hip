@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <utility>
 #include <string>
 
 #include "blocksolve.hpp"
@@ -45,7 +46,22 @@ constexpr int kH = 32;   // tile edge: a block is two halves of 32 links
 constexpr int kMS = 36;  // LDS row stride (floats) of a 32x32 tile: 16-byte aligned rows, odd in float4 units
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// native vectors: a float4 (a struct) is copied with memcpy, and an array of them written that way stayed in scratch;
+// pairs of them feed v_pk_fma_f32 (two FMAs an issue slot) straight from the registers a 16-byte LDS read filled
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 lds4(const float4 *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 dup2(float v) { return f32x2{v, v}; }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// v[l] + v[l ^ 16] in every lane
+__device__ __forceinline__ float row_pair_sum(float v) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
 
 // v[l & 31] + v[(l & 31) + 32] in every lane
 __device__ __forceinline__ float half_sum(float v) {
@@ -67,6 +83,10 @@ __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.
 #ifndef CU2REC_BS_TRACE
 #define CU2REC_BS_TRACE 0
 #endif
+#ifndef CU2REC_BS_ABLATE  // timing-only builds (tools/build_variant.sh): 1 no global stores in the solver's loop, 2 no (C) products,
+                          // 4 the loaders do not write user rows into LDS, 8 no (A) products, 16 no (B) products
+#define CU2REC_BS_ABLATE 0
+#endif
 constexpr int kStampWords = 8;
 struct WaveStamp {
     unsigned long long t0;
@@ -87,7 +107,9 @@ struct WaveStamp {
         const int seg = it.stamps_cap / 8;  // one segment of the buffer per kernel: no atomics, no contention
         if (id >= seg) return;
         unsigned long long *r = it.stamps + 1 + kStampWords * (static_cast<size_t>(kernel) * seg + id);
-        r[0] = static_cast<unsigned long long>(kernel);
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        r[0] = static_cast<unsigned long long>(kernel) | (static_cast<unsigned long long>(xcc & 15u) << 32);
         r[1] = static_cast<unsigned long long>(id);
         r[2] = t0;
         r[3] = wall_clock64();
@@ -181,6 +203,11 @@ __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict
 // products for M21 are matrix-core work again, the first one's accumulator tile being the second one's B operand as it
 // stands.
 constexpr int kGramTabFloats = 2 * kB;  // a^d | c^d, d in [0, 64)
+constexpr int kWS = 130;                // floats per row of W in LDS: rows 16 apart land 32 banks apart
+constexpr int kGramExtFloats = kB * kWS - 2 * kH * kMS;
+__device__ __forceinline__ bool block_is_affine(const BsIteration &it, const BsBlockDesc &bd) {
+    return it.aff_min_blocks > 0 && (it.chains[bd.chain].len + kB - 1) / kB >= it.aff_min_blocks;
+}
 __device__ __forceinline__ size_t gram_tile_float4s(int nslots) { return static_cast<size_t>(kB) * (nslots | 1); }
 
 __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it) {
@@ -192,15 +219,20 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
     if (bd.n_valid == 0) return;
     const int nslots = a.nslots, RS = nslots | 1;
     float4 *tile = bs_smem;  // [kB][RS]
-    float *Ns = reinterpret_cast<float *>(bs_smem + gram_tile_float4s(nslots));  // N00 | N11 | N10
-    float *Ms = Ns + 3 * kH * kMS;                                                // M11 | M22
-    float *tab = Ms + 2 * kH * kMS;
+    float *Ms = reinterpret_cast<float *>(bs_smem + gram_tile_float4s(nslots));  // M11 | M22
+    float *Ns = Ms + 2 * kH * kMS;                                                // N00 (later M21) | N11 | N10
+    float *Ws = Ns + kH * kMS;                // affine form: W [kB][kWS] takes over N11 | N10 and the extension behind
+    float *tab = Ms + 5 * kH * kMS + (bs_affine_supported(nslots) ? kGramExtFloats : 0);
+    float *basev = tab + kGramTabFloats;      // [kB] r - gb - ub, 0 past the end of a short block
     const bool mine = lane < bd.n_valid;  // lane l: link l
     const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
     const int x = static_cast<int>(val >> 32);
+    const bool affine = block_is_affine(it, bd);  // workgroup uniform
     if (wave == 3) {
-        if (mine)  // what the link's error starts from: r - gb - ub (mf_sequential.cu:119-126 without b and p.q)
-            it.base[bd.pos0 + lane] = (__uint_as_float(static_cast<uint32_t>(val)) - a.global_bias) - a.user_bias[x];
+        // what the link's error starts from: r - gb - ub (mf_sequential.cu:119-126 without b and p.q)
+        const float r0 = (__uint_as_float(static_cast<uint32_t>(val)) - a.global_bias) - a.user_bias[x];
+        if (mine) it.base[bd.pos0 + lane] = r0;
+        basev[lane] = mine ? r0 : 0.f;
         tab[lane] = it.tables[kTabApow + lane];
         tab[kB + lane] = it.tables[kTabCpow + lane];
     }
@@ -271,10 +303,11 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
     }
     __syncthreads();
     stamp.mark(it, 2);
-    if (wave != 0) {
+    if (wave != 0 && !affine) {
         stamp.done(it, 1, 4 * g + wave);
         return;
     }
+    if (wave == 0) {
     // M11 (lanes 0-31) and M22 (lanes 32-63): lane = column, m[kk] = M[kk][column]
     float m[kH];
     {
@@ -337,9 +370,117 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
         }
     }
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) Mg[kH * kH + acc_row(reg, h) * kH + k] = -macc[reg];
+    for (int reg = 0; reg < 16; ++reg) {
+        Mg[kH * kH + acc_row(reg, h) * kH + k] = -macc[reg];
+        if (affine) Ns[acc_row(reg, h) * kMS + k] = -macc[reg];  // M21 where N00 was
+    }
     stamp.mark(it, 3);
-    stamp.done(it, 1, 4 * g);
+    }  // wave 0
+    if (!affine) {
+        stamp.done(it, 1, 4 * g);
+        return;
+    }
+    // ---- affine form of the block (long chains) ------------------------------------------------------------------------
+    // state s = (item row, item bias), user rows extended by a one, Lambda = diag(a, ..., a, c):
+    //     e = M (r' - G s0),  G_k = Lambda^k (p_k, 1);   s_end = Lambda^n s0 + lr H^T e,  H_j = Lambda^(n-1-j) (p_j, 1)
+    //     =>  s_end = Lambda^n s0 - lr T' (s0, -1),  T' = H^T W,  W = M [G | r'],  e = -W (s0, -1)
+    // (tests/test_blocksolve_algebra.py, affine_chain).  W: wavefront w takes columns 32 w ..; T': wavefront w takes rows
+    // 32 w .. and all four column tiles; both contract over the 64 links in steps of two (one per lane half).
+    __syncthreads();
+    {
+        const int F4 = 4 * nslots, FX = F4 + 2, TS = bs_affine_ts(nslots), RS4 = 4 * RS;
+        const float *tilef = reinterpret_cast<const float *>(tile);
+        const float *M21s = Ns;
+        const int n = bd.n_valid;
+        float *Wg = it.Wbuf + static_cast<size_t>(g) * bs_affine_w_floats(nslots);
+        float *Tg = it.Tbuf + static_cast<size_t>(g) * bs_affine_t_floats(nslots);
+        if (32 * wave < FX) {
+            const int jc = 32 * wave + k;
+            float bl[16], bu[16], m11[16], m21[16], m22[16];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const float4 x11 = *reinterpret_cast<const float4 *>(Ms + k * kMS + 16 * h + 4 * t4);
+                const float4 x22 = *reinterpret_cast<const float4 *>(Ms + (kH + k) * kMS + 16 * h + 4 * t4);
+                const float4 x21 = *reinterpret_cast<const float4 *>(M21s + k * kMS + 16 * h + 4 * t4);
+                m11[4 * t4] = x11.x, m11[4 * t4 + 1] = x11.y, m11[4 * t4 + 2] = x11.z, m11[4 * t4 + 3] = x11.w;
+                m22[4 * t4] = x22.x, m22[4 * t4 + 1] = x22.y, m22[4 * t4 + 2] = x22.z, m22[4 * t4 + 3] = x22.w;
+                m21[4 * t4] = x21.x, m21[4 * t4 + 1] = x21.y, m21[4 * t4 + 2] = x21.z, m21[4 * t4 + 3] = x21.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int kl = 16 * h + s, ku = kH + kl;
+                const float pl = tilef[kl * RS4 + min(jc, F4 - 1)], pu = tilef[ku * RS4 + min(jc, F4 - 1)];
+                const float cl = kl < n ? tab[kB + kl] : 0.f, cu = ku < n ? tab[kB + ku] : 0.f;
+                bl[s] = jc < F4 ? pl * tab[kl] : jc == F4 ? cl : jc == F4 + 1 ? basev[kl] : 0.f;
+                bu[s] = jc < F4 ? pu * tab[ku] : jc == F4 ? cu : jc == F4 + 1 ? basev[ku] : 0.f;
+            }
+            f32x16 wt, wb;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) wt[i] = wb[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                wt = __builtin_amdgcn_mfma_f32_32x32x2f32(m11[s], bl[s], wt, 0, 0, 0);
+                wb = __builtin_amdgcn_mfma_f32_32x32x2f32(m21[s], bl[s], wb, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) wb = __builtin_amdgcn_mfma_f32_32x32x2f32(m22[s], bu[s], wb, 0, 0, 0);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r0 = acc_row(reg, h), r1 = kH + r0;
+                Ws[r0 * kWS + jc] = wt[reg];
+                Ws[r1 * kWS + jc] = wb[reg];
+                if (jc < TS) {
+                    Wg[r0 * TS + jc] = wt[reg];
+                    Wg[r1 * TS + jc] = wb[reg];
+                }
+            }
+        }
+        __syncthreads();
+        const int R = F4 + 1;
+        if (32 * wave < R) {
+            const int i = 32 * wave + k, ic = min(i, F4 - 1);
+            const int NJ = (FX + 31) >> 5;
+            f32x16 acc[4];
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[J][r] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+                for (int s4 = 0; s4 < 16; s4 += 4) {
+                    float av[4], bv[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int kl = kH * kh + 16 * h + s4 + u;
+                        const int back = max(n - 1 - kl, 0);
+                        const float pv = tilef[kl * RS4 + ic];
+                        av[u] = i < F4 ? pv * tab[back] : (i == F4 && kl < n ? tab[kB + back] : 0.f);
+#pragma unroll
+                        for (int J = 0; J < 4; ++J) bv[J][u] = Ws[kl * kWS + min(32 * J + k, 127)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int J = 0; J < 4; ++J)
+                            if (J < NJ) acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[J][u], acc[J], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int J = 0; J < 4; ++J) {
+                const int col = 32 * J + k;
+                if (J < NJ && col < TS) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int row = 32 * wave + acc_row(reg, h);
+                        if (row < R) Tg[static_cast<size_t>(row) * TS + col] = acc[J][reg];
+                    }
+                }
+            }
+        }
+    }
+    stamp.done(it, 1, 4 * g + wave);
 }
 
 // ---- phase 2: the chains ----------------------------------------------------------------------------------------------
@@ -356,8 +497,8 @@ constexpr int kDepth = 4;  // blocks a loader keeps in flight
 
 template <int N>
 struct Stage {  // one loader thread's share of a block
-    float4 rows[N];
-    float4 m4[4];
+    f32x4 rows[N];
+    f32x4 m4[3];
     float base;
     uint64_t next_val;  // the thread's schedule entry of the block this stage loads next (kDepth blocks on)
 };
@@ -365,57 +506,261 @@ struct Stage {  // one loader thread's share of a block
 // LDS slot: [kB][RS] float4 user rows | three factor tiles, rows of kMS floats (column 32 of the first 64 rows: the base error)
 __host__ __device__ inline int solve_slot_f4(int nslots) { return kB * (nslots | 1) + 3 * kH * kMS / 4; }
 
-// after the ring: the item row (4 * sw + 8 float4, zero beyond the row), rhs, w, the decay tables
+// after the ring: the item row (4 * sw + 8 float4, zero beyond the row), the partial dots and errors, four copies of rhs
+// and w, the decay tables, a row of zeros
 __host__ __device__ inline size_t solve_lds_bytes(int nslots, int sw) {
-    return (static_cast<size_t>(kRing) * solve_slot_f4(nslots) + 4 * sw + 8 + kB / 4 + kB / 4 + (kBsTableFloats + 3) / 4) * 16;
+    return (static_cast<size_t>(kRing) * solve_slot_f4(nslots) + 4 * sw + 8 + 2 * kB + 8 * kB / 4 + (kBsTableFloats + 3) / 4 + 8 + 1) * 16;
 }
 
-// Four wavefronts = one per SIMD.
-template <int SW>  // float4 slots per row, rounded up to a multiple of 4: 4 * SW >= nslots
-__global__ __launch_bounds__(256) void bs_solve_kernel(SgdArgs a, BsIteration it) {
+// ---- phase 2, long chains: the affine form ----------------------------------------------------------------------------
+// Phase 1 left T' of every block of the chain (bs_gram_kernel): the block maps the state s = (item row, item bias) to
+// Lambda^n s - lr T' (s, -1).  One wavefront applies it (lane l: rows l and 64 + l of T' against the state, broadcast
+// from LDS), three wavefronts stream the T' blocks (contiguous, (4 nslots + 1) x bs_affine_ts floats) into a ring of two
+// LDS slots, two more blocks in flight in their registers.  The start state of every block goes to phase 3, which
+// recovers the block's errors from it (e = -W (s0, -1)).
+constexpr int kRingA = 2, kDepthA = 2;
+__host__ __device__ inline int affine_block_f4(int nslots) { return (4 * nslots + 1) * ((nslots + 1) | 1); }
+__host__ __device__ inline size_t affine_lds_bytes(int nslots) {
+    return (static_cast<size_t>(kRingA) * affine_block_f4(nslots) + ((nslots + 1) | 1) + 1) * 16;
+}
+
+// a loader thread's share of block t: float4 numbers lt, lt + 192, ... (written as pack expansions: the stages must
+// stay in registers, and a loop the compiler decides not to unroll would put them in scratch memory).  Every load is
+// unconditional at a clamped address, see the loader of the other chains.
+template <int N, int... I>
+__device__ __forceinline__ void aff_issue(f32x4 (&st)[N], const float4 *Tsrc, int t, int nblk, int total4, int lt,
+                                          std::integer_sequence<int, I...>) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsrc + static_cast<size_t>(min(t, nblk - 1)) * total4);
+    ((st[I] = src[min(lt + 192 * I, total4 - 1)]), ...);
+}
+template <int N, int... I>
+__device__ __forceinline__ void aff_commit(const f32x4 (&st)[N], float4 *dst4, int total4, int lt, std::integer_sequence<int, I...>) {
+    f32x4 *dst = reinterpret_cast<f32x4 *>(dst4);
+    ((lt + 192 * I < total4 ? (void)(dst[lt + 192 * I] = st[I]) : (void)0), ...);
+}
+
+template <int SW>
+__device__ __forceinline__ void bs_affine_chain(const SgdArgs &a, const BsIteration &it, const BsChainDesc &cd, float4 *smem,
+                                                WaveStamp &stamp) {
+    constexpr int kNs = 4 * SW < 31 ? 4 * SW : 31;
+    constexpr int NA = ((4 * kNs + 1) * ((kNs + 1) | 1) + 191) / 192;  // float4 per loader thread and block
+    const int nslots = a.nslots, F4 = 4 * nslots, R = F4 + 1, n4 = (nslots + 1) | 1;
+    const int total4 = R * n4;
+    const int len = cd.len, nblk = (len + kB - 1) / kB, g0 = cd.blk0;
+    const int n_intervals = (nblk + kDepthA - 1) / kDepthA * kDepthA;
+    const int tid = threadIdx.x;
+    const float4 *Tsrc = reinterpret_cast<const float4 *>(it.Tbuf) + static_cast<size_t>(g0) * total4;
+    if (tid >= 64) {
+        const int lt = tid - 64;
+        f32x4 sa[NA], sb[NA];  // two blocks in flight
+        aff_issue(sa, Tsrc, 0, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
+        aff_issue(sb, Tsrc, 1, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
+        aff_commit(sa, smem, total4, lt, std::make_integer_sequence<int, NA>{});
+        aff_issue(sa, Tsrc, 2, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
+        __syncthreads();
+        static_assert(kDepthA == 2 && kRingA == 2, "the loop below is written out for two stages and two slots");
+        for (int m0 = 0; m0 < n_intervals; m0 += 2) {
+            aff_commit(sb, smem + total4, total4, lt, std::make_integer_sequence<int, NA>{});  // block m0 + 1
+            aff_issue(sb, Tsrc, m0 + 3, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
+            __syncthreads();
+            aff_commit(sa, smem, total4, lt, std::make_integer_sequence<int, NA>{});  // block m0 + 2
+            aff_issue(sa, Tsrc, m0 + 4, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
+            __syncthreads();
+        }
+        stamp.done(it, 3, static_cast<int>(blockIdx.x) * 4 + (tid >> 6));
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const int l = tid;
+    const int y = cd.item;
+    float *sbuf = reinterpret_cast<float *>(smem + kRingA * total4);  // [4 n4]: (s, -1, 0 ...)
+    const float4 *sb4 = reinterpret_cast<const float4 *>(sbuf);
+    const int i0 = l, i1 = kB + l;
+    const int rc0 = min(i0, R - 1), rc1 = min(i1, R - 1);
+    const float q0v = a.Q[static_cast<size_t>(y) * a.ldq + min(i0, F4 - 1)], q1v = a.Q[static_cast<size_t>(y) * a.ldq + min(i1, F4 - 1)];
+    const float bv = a.item_bias[y];
+    float s0 = i0 < F4 ? q0v : i0 == F4 ? bv : 0.f;
+    float s1 = i1 < F4 ? q1v : i1 == F4 ? bv : 0.f;
+    for (int j = l; j < 4 * n4; j += 64) {
+        const float sj = j == i0 ? s0 : s1;  // j = l or 64 + l; past the state: the constant -1, then zeros
+        sbuf[j] = j <= F4 ? sj : j == F4 + 1 ? -1.f : 0.f;
+    }
+    const float lr = a.h.lr;
+    const int n_last = len - kB * (nblk - 1);
+    const float adel_full = it.tables[kTabAdel + kB], cdel_full = it.tables[kTabCdel + kB];
+    const float adel_last = it.tables[kTabAdel + n_last], cdel_last = it.tables[kTabCdel + n_last];
+    const int NC = (n4 + 3) >> 2;  // chunks of four 16-byte columns
+    __syncthreads();
+    for (int m = 0; m < n_intervals; ++m) {
+        if (m < nblk) {  // workgroup uniform
+            const bool last = m == nblk - 1;
+            const float del0 = i0 < F4 ? (last ? adel_last : adel_full) : (last ? cdel_last : cdel_full);
+            const float del1 = i1 < F4 ? (last ? adel_last : adel_full) : (last ? cdel_last : cdel_full);
+            if (i0 < F4) it.qstart[static_cast<size_t>(g0 + m) * a.ldq + i0] = s0;
+            if (i1 < F4) it.qstart[static_cast<size_t>(g0 + m) * a.ldq + i1] = s1;
+            if (i0 == F4) it.bstart[g0 + m] = s0;
+            if (i1 == F4) it.bstart[g0 + m] = s1;
+            const float4 *T4 = smem + (m % kRingA) * total4;
+            const float4 *r0 = T4 + rc0 * n4, *r1 = T4 + rc1 * n4;
+            float4 a0 = zero4(), a1 = zero4();
+            float4 ta[2][4], tb[2][4], sv[2][4];
+            auto load = [&](int buf, int ch) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * ch + i, cc = min(c, n4 - 1);
+                    ta[buf][i] = r0[cc];
+                    tb[buf][i] = r1[cc];
+                    const float4 v = sb4[cc];
+                    sv[buf][i] = c < n4 ? v : zero4();
+                }
+            };
+            auto fma8 = [&](int buf) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a0.x = __builtin_fmaf(ta[buf][i].x, sv[buf][i].x, a0.x);
+                    a1.x = __builtin_fmaf(tb[buf][i].x, sv[buf][i].x, a1.x);
+                    a0.y = __builtin_fmaf(ta[buf][i].y, sv[buf][i].y, a0.y);
+                    a1.y = __builtin_fmaf(tb[buf][i].y, sv[buf][i].y, a1.y);
+                    a0.z = __builtin_fmaf(ta[buf][i].z, sv[buf][i].z, a0.z);
+                    a1.z = __builtin_fmaf(tb[buf][i].z, sv[buf][i].z, a1.z);
+                    a0.w = __builtin_fmaf(ta[buf][i].w, sv[buf][i].w, a0.w);
+                    a1.w = __builtin_fmaf(tb[buf][i].w, sv[buf][i].w, a1.w);
+                }
+            };
+            load(0, 0);
+            for (int ch = 0; ch < NC; ch += 2) {
+                load(1, ch + 1);  // past the last chunk: clamped addresses, zero weights
+                __builtin_amdgcn_sched_barrier(0);
+                fma8(0);
+                __builtin_amdgcn_sched_barrier(0);
+                load(0, ch + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                fma8(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float t0 = (a0.x + a0.y) + (a0.z + a0.w), t1 = (a1.x + a1.y) + (a1.z + a1.w);
+            s0 = i0 < R ? (s0 - del0 * s0) - lr * t0 : 0.f;
+            s1 = i1 < R ? (s1 - del1 * s1) - lr * t1 : 0.f;
+            __builtin_amdgcn_wave_barrier();  // every lane has read the old state
+            if (i0 < R) sbuf[i0] = s0;
+            if (i1 < R) sbuf[i1] = s1;
+        }
+        __syncthreads();
+    }
+    if (i0 < F4) a.Q[static_cast<size_t>(y) * a.ldq + i0] = s0;
+    if (i1 < F4) a.Q[static_cast<size_t>(y) * a.ldq + i1] = s1;
+    if (i0 == F4) a.item_bias[y] = s0;
+    if (i1 == F4) a.item_bias[y] = s1;
+    stamp.done(it, 2, static_cast<int>(blockIdx.x) * 4);
+}
+
+// ---- phase 2, beside the chains: warm the solver's L2 ------------------------------------------------------------------
+// A chain is advanced by ONE CU, and what that CU can pull through the fabric (the user rows were last touched by
+// phase 1 on other XCDs) bounds the chain: about 20 GB/s measured, 37 KB a block.  Workgroups are dealt round robin over
+// the 8 XCDs, so workgroup c (chain c) and the helper workgroups n_hot_pad + 8 j + (c & 7) share an L2; the helpers
+// read the blocks of the chain (every pf_helpers-th block each) ahead of the solver and throw the data away.  If the
+// placement assumption does not hold the reads are merely useless.
+__device__ __forceinline__ void bs_warm_l2(const SgdArgs &a, const BsIteration &it, int hb) {
+    const int xcd = hb & 7, j = hb >> 3;
+    const int c = xcd + 8 * (j / it.pf_helpers), hidx = j % it.pf_helpers;
+    if (c >= it.n_hot) return;
+    const BsChainDesc cd = it.chains[c];
+    if (cd.len <= 0) return;
+    const int nblk = (cd.len + kB - 1) / kB;
+    const int t = threadIdx.x, row = t >> 2;
+    uint32_t acc = 0;
+    for (int m = hidx; m < nblk; m += it.pf_helpers) {
+        const uint64_t val = it.vals[cd.begin + min(kB * m + row, cd.len - 1)];
+        const float4 *src = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(static_cast<uint32_t>(val >> 32)) * a.ldp);
+        for (int slot = t & 3; slot < a.nslots; slot += 4) acc ^= __float_as_uint(src[slot].x);
+        const float4 *mg = reinterpret_cast<const float4 *>(it.Mbuf + static_cast<size_t>(cd.blk0 + m) * kBsFactorFloats);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc ^= __float_as_uint(mg[q * 256 + t].x);
+        if (t < kB) acc ^= __float_as_uint(it.base[cd.begin + min(kB * m + t, cd.len - 1)]);
+    }
+    asm volatile("" ::"v"(acc));  // the loads are the point
+}
+
+// The four solver wavefronts meet twice inside a block; s_barrier would drag the loaders along (their work of an interval
+// -- 25 KB of LDS writes, a few hundred cache-line requests -- would then sit on the chain's critical path), so they count
+// arrivals in LDS instead.  LDS operations of a wavefront complete in order: the partial results written before the
+// ds_add are visible to whoever sees the count.
+__device__ __forceinline__ void solvers_meet(unsigned *meet, unsigned target, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(meet, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(meet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Eight wavefronts: four solvers (one per SIMD) and four loaders.
+//   loaders: stream the chain's blocks (64 user rows, the factor tiles, the base errors) into a ring of two LDS slots,
+//            kDepth blocks in flight in their registers; every load unconditional at a clamped address.
+//   solvers: all four hold the same 64 links (lane = link) and split every step of a block four ways:
+//     (A) d_k = p_k . q      each wavefront a quarter of the row (SW slots), partial sums through LDS            -- meet
+//     (B) e = M rhs          each wavefront 16 columns of M (rhs is cheap and computed four times), partials     -- meet
+//     (C) q <- a^n q + sum_k w_k p_k   each wavefront its quarter of the row: lane = (slot, group of 8 links), the
+//                            eight groups summed across lanes (DPP row rotate, permlane16/32 swaps)              -- barrier
+//            (the barrier is the one per block all eight wavefronts share: it hands the ring slot back to the loaders)
+//   One wavefront doing all of it issued ~500 instructions per block and took 1.35 us of the block's 1.8 us; the
+//   loaders alone sustain a block per 0.42 us (tools/build_variant.sh ablations, profiles/README.md).
+template <int SW>  // float4 slots per row quarter: 4 * SW >= nslots
+__global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it) {
     extern __shared__ float4 bs_smem[];
     WaveStamp stamp(it);
+    const int n_hot_pad = (it.n_hot + 7) & ~7;
+    if (static_cast<int>(blockIdx.x) >= n_hot_pad) {
+        if (threadIdx.x < 256) bs_warm_l2(a, it, static_cast<int>(blockIdx.x) - n_hot_pad);
+        stamp.done(it, 6, static_cast<int>(blockIdx.x) - n_hot_pad);
+        return;
+    }
+    if (static_cast<int>(blockIdx.x) >= it.n_hot) return;
     const BsChainDesc cd = it.chains[blockIdx.x];
     const int begin = cd.begin, len = cd.len;
     if (len <= 0) return;  // workgroup uniform
     const int nblk = (len + kB - 1) / kB;
+    if (it.aff_min_blocks > 0 && nblk >= it.aff_min_blocks) {  // workgroup uniform
+        if (threadIdx.x >= 256) return;  // the affine form is written for four wavefronts
+        bs_affine_chain<SW>(a, it, cd, bs_smem, stamp);
+        return;
+    }
     const int g0 = cd.blk0;
     const int nslots = a.nslots, RS = nslots | 1;  // odd row stride (in float4): conflict-free ds_read_b128 down a column
     const int S4 = solve_slot_f4(nslots);
     const bool long_chain = nblk > kDepth;
-    const int n_intervals = long_chain ? (nblk + kDepth - 1) / kDepth * kDepth : kDepth;  // both roles: this many barriers
+    const int n_intervals = long_chain ? (nblk + kDepth - 1) / kDepth * kDepth : kDepth;  // both roles: 3 barriers each
     float4 *smem = bs_smem;
     const int tid = threadIdx.x;
 
-    if (tid >= 64) {
+    if (tid >= 256) {
         // ------------------------------------------------------------------------------------------ loader
-        constexpr int NLT = (4 * SW + 2) / 3;  // float4 per loader thread and block: slots tp, tp + 3, ...
-        const int lt = tid - 64, tr = lt / 3, tp = lt - 3 * tr;
+        constexpr int NLT = SW;  // float4 per loader thread and block: slots tp, tp + 4, ...
+        const int lt = tid - 256, tr = lt >> 2, tp = lt & 3;
         auto load_val = [&](int t) -> uint64_t { return it.vals[begin + min(kB * t + tr, len - 1)]; };
         // every load is unconditional (clamped addresses): a branch or a predicated load inside the ring would make the
         // compiler's s_waitcnt pass fall back to vmcnt(0) and serialise the ring
         auto issue = [&](Stage<NLT> &s, int t, uint64_t val) {
             s.next_val = load_val(t + kDepth);
-            const float4 *row = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(static_cast<uint32_t>(val >> 32)) * a.ldp);
+            const f32x4 *row = reinterpret_cast<const f32x4 *>(a.P + static_cast<size_t>(static_cast<uint32_t>(val >> 32)) * a.ldp);
 #pragma unroll
-            for (int i = 0; i < NLT; ++i) s.rows[i] = row[min(tp + 3 * i, nslots - 1)];
-            const float4 *mg = reinterpret_cast<const float4 *>(it.Mbuf + static_cast<size_t>(g0 + min(t, nblk - 1)) * kBsFactorFloats);
+            for (int i = 0; i < NLT; ++i) s.rows[i] = (CU2REC_BS_ABLATE & 32) ? f32x4{0.01f, 0.01f, 0.01f, 0.01f} : row[min(tp + 4 * i, nslots - 1)];
+            const f32x4 *mg = reinterpret_cast<const f32x4 *>(it.Mbuf + static_cast<size_t>(g0 + min(t, nblk - 1)) * kBsFactorFloats);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s.m4[q] = mg[q * 192 + lt];
+            for (int q = 0; q < 3; ++q) s.m4[q] = mg[q * 256 + lt];
             s.base = it.base[begin + min(kB * t + (lt & 63), len - 1)];
         };
         auto commit = [&](const Stage<NLT> &s, int t) {  // block t -> ring slot t % kRing; links beyond the chain: zero rows
-            float4 *sl = smem + (t % kRing) * S4;
+            f32x4 *sl = reinterpret_cast<f32x4 *>(smem + (t % kRing) * S4);
             const bool rv = kB * t + tr < len;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NLT; ++i) {
-                const int slot = tp + 3 * i;
-                if (slot < nslots) sl[tr * RS + slot] = rv ? s.rows[i] : zero4();
+                const int slot = tp + 4 * i;
+                if (!(CU2REC_BS_ABLATE & 4) && slot < nslots) sl[tr * RS + slot] = rv ? s.rows[i] : z;
             }
-            float4 *mt = sl + kB * RS;  // three tiles of 32 rows x 8 float4, rows kMS floats apart
+            f32x4 *mt = sl + kB * RS;  // three tiles of 32 rows x 8 float4, rows kMS floats apart
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int item = q * 192 + lt;  // float4 number inside the block's factor
+            for (int q = 0; q < 3; ++q) {
+                const int item = q * 256 + lt;  // float4 number inside the block's factor
                 mt[(item >> 3) * (kMS / 4) + (item & 7)] = s.m4[q];
             }
             if (lt < kB) reinterpret_cast<float *>(mt)[lt * kMS + kH] = kB * t + lt < len ? s.base : 0.f;
@@ -435,13 +780,9 @@ __global__ __launch_bounds__(256) void bs_solve_kernel(SgdArgs a, BsIteration it
                 for (int u = 0; u < kDepth; ++u) {
                     const int m = m0 + u;
                     Stage<NLT> &s = st[(u + 1) % kDepth];
-                    if (m == 8) stamp.mark(it, 0);
                     commit(s, m + 1);
-                    if (m == 8) stamp.mark(it, 1);
                     issue(s, m + 1 + kDepth, s.next_val);
                     __syncthreads();
-                    if (m == 8) stamp.mark(it, 2);
-                    if (m == 9) stamp.mark(it, 3);
                 }
             }
         } else {  // everything the chain needs is requested at once
@@ -456,29 +797,38 @@ __global__ __launch_bounds__(256) void bs_solve_kernel(SgdArgs a, BsIteration it
                 __syncthreads();
             }
         }
-        stamp.done(it, 3, static_cast<int>(blockIdx.x) * 4 + (tid >> 6));
+        stamp.done(it, 3, static_cast<int>(blockIdx.x) * 4 + ((tid >> 6) & 3));
         return;
     }
 
-    // ---------------------------------------------------------------------------------------------- solver
+    // ---------------------------------------------------------------------------------------------- solvers
     __builtin_amdgcn_s_setprio(3);  // the chain is the critical path of the iteration; whatever shares the CU is not
-    const int k = tid;  // lane = link
-    constexpr int NPS = (SW + 7) / 8;  // passes of 32 slots over the item row
+    const int w = tid >> 6, k = tid & 63;  // wavefront = quarter, lane = link
+    constexpr int NP = (SW + 7) / 8;       // passes of 8 slots over this wavefront's quarter of the item row
     float4 *qrow = smem + kRing * S4;                              // [4 * SW + 8]: the item row, zero beyond it
-    float *rbuf = reinterpret_cast<float *>(qrow + 4 * SW + 8);    // [kB]: rhs
-    float *wbuf = rbuf + kB;                                       // [kB]: w
-    float *tab = wbuf + kB;                                        // [kBsTableFloats]
-    for (int i = k; i < kBsTableFloats; i += 64) tab[i] = it.tables[i];
+    float4 *dpart = qrow + 4 * SW + 8;                             // [kB]: link k's four partial dot products
+    float4 *epart = dpart + kB;                                    // [kB]: link k's four partial errors
+    float *rbuf = reinterpret_cast<float *>(epart + kB) + w * kB;  // [4][kB]: rhs, one copy per wavefront
+    float *wbuf = reinterpret_cast<float *>(epart + kB) + (4 + w) * kB;  // [4][kB]: w, one copy per wavefront
+    float *tab = reinterpret_cast<float *>(epart + kB) + 8 * kB;   // [kBsTableFloats]
+    float4 *zrow = reinterpret_cast<float4 *>(tab) + (kBsTableFloats + 3) / 4;  // [8] zeros
+    unsigned *meet = reinterpret_cast<unsigned *>(zrow + 8);                    // [1] arrivals at the solvers' meeting points
+    if (w == 0) {
+        for (int i = k; i < kBsTableFloats; i += 64) tab[i] = it.tables[i];
+        if (k < 8) zrow[k] = zero4();
+        if (k == 0) *meet = 0u;
+    }
+    unsigned met = 0;
     const int y = cd.item;
-    const int sl = k & 31, kp = k >> 5;  // transposed mat-vec: lane (slot sl of the pass, link half kp)
-    float4 q4[NPS];                      // the item row, slot 32 p + sl (both lane halves hold it)
-    const float4 *qsrc = reinterpret_cast<const float4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
+    const int sl = k & 7, kg = k >> 3;  // (C): lane (slot sl of the pass, links 8 kg .. 8 kg + 7)
+    f32x4 q4[NP];                       // this wavefront's quarter of the item row, slot w SW + 8 p + sl (every kg holds it)
+    const f32x4 *qsrc = reinterpret_cast<const f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
 #pragma unroll
-    for (int p = 0; p < NPS; ++p) {
-        const int slot = 32 * p + sl;
-        const float4 v = qsrc[min(slot, nslots - 1)];
-        q4[p] = slot < nslots ? v : zero4();
-        if (kp == 0 && slot < 4 * SW + 8) qrow[slot] = q4[p];
+    for (int p = 0; p < NP; ++p) {
+        const int sq = 8 * p + sl, slot = w * SW + sq;
+        const f32x4 v = qsrc[min(slot, nslots - 1)];
+        q4[p] = sq < SW && slot < nslots ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kg == 0 && sq < SW) *reinterpret_cast<f32x4 *>(qrow + slot) = q4[p];
     }
     float b = a.item_bias[y];
     const float lr = a.h.lr;
@@ -486,157 +836,122 @@ __global__ __launch_bounds__(256) void bs_solve_kernel(SgdArgs a, BsIteration it
     const bool upper = k >= kH;
     __syncthreads();
     for (int m = 0; m < n_intervals; ++m) {
-        if (m < nblk) {  // workgroup uniform
-            const int n = min(kB, len - kB * m);
-            const float4 *tile = smem + (m % kRing) * S4;
-            const float *Mt = reinterpret_cast<const float *>(tile + kB * RS);
-            // this lane's row of M: links 0-31 [M11 row | 0], links 32-63 [M21 row | M22 row]
-            float4 ma[8], mb[8];
-            {
-                const float4 *ra = reinterpret_cast<const float4 *>(Mt + ((upper ? kH : 0) + kr) * kMS);
-                const float4 *rb = reinterpret_cast<const float4 *>(Mt + (2 * kH + kr) * kMS);
+        const bool live = m < nblk;  // workgroup uniform
+        const int n = min(kB, len - kB * m);
+        const float4 *tile = smem + (m % kRing) * S4;
+        const float *Mt = reinterpret_cast<const float *>(tile + kB * RS);
+        float base = 0.f, adel_k = 0.f, cdel_k = 0.f, apr = 0.f, cpr = 0.f, adel_n = 0.f, cdel_n = 0.f;
+        f32x4 mq[4];
+        if (live) {
+            // this lane's 16 columns of its row of M: links 0-31 [M11 row | 0], links 32-63 [M21 row | M22 row]
+            const float4 *mrow = w < 2 ? reinterpret_cast<const float4 *>(Mt + ((upper ? kH : 0) + kr) * kMS + 16 * w)
+                                       : (upper ? reinterpret_cast<const float4 *>(Mt + (2 * kH + kr) * kMS + 16 * (w - 2)) : zrow);
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    ma[t] = ra[t];
-                    const float4 v = rb[t];
-                    mb[t] = upper ? v : zero4();
-                }
-            }
-            const float base = Mt[k * kMS + kH];
+            for (int t = 0; t < 4; ++t) mq[t] = lds4(mrow + t);
+            base = Mt[k * kMS + kH];
             const int back = max(n - 1 - k, 0);
-            const float adel_k = tab[kTabAdel + k], cdel_k = tab[kTabCdel + k];
-            const float apr = tab[kTabApow + back], cpr = tab[kTabCpow + back];
-            const float adel_n = tab[kTabAdel + n], cdel_n = tab[kTabCdel + n];
-            if (m == 8) stamp.mark(it, 0);
-            // (A) every link's row against the item row.  Chunks of eight slots, the next chunk's sixteen LDS reads issued
-            // before this chunk's products (the scheduling barriers keep the compiler from sinking the reads next to
-            // their uses: LDS latency, not issue, is what it would pay), four accumulators; slots beyond the row
-            // multiply the item row's zero padding
-            float d;
-            {
-                constexpr int NC = (4 * SW + 7) / 8;
-                float4 pbuf[2][8], qbuf[2][8];
-                const float4 *prow = tile + k * RS;
-                float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            adel_k = tab[kTabAdel + k], cdel_k = tab[kTabCdel + k];
+            apr = tab[kTabApow + back], cpr = tab[kTabCpow + back];
+            adel_n = tab[kTabAdel + n], cdel_n = tab[kTabCdel + n];
+            // (A) this wavefront's quarter of every link's row against the item row; slots beyond the row multiply the
+            // item row's zero padding
+            const float4 *prow = tile + k * RS;
+            f32x4 pv[SW], qv[SW];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    pbuf[0][i] = prow[min(i, nslots - 1)];
-                    qbuf[0][i] = qrow[i];
-                }
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    if (c + 1 < NC) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            pbuf[(c + 1) & 1][i] = prow[min(8 * (c + 1) + i, nslots - 1)];
-                            qbuf[(c + 1) & 1][i] = qrow[8 * (c + 1) + i];
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < 8; i += 4) {
-                        const float4 *pp = &pbuf[c & 1][i], *qq = &qbuf[c & 1][i];
-                        d0 = __builtin_fmaf(pp[0].x, qq[0].x, d0);
-                        d1 = __builtin_fmaf(pp[1].x, qq[1].x, d1);
-                        d2 = __builtin_fmaf(pp[2].x, qq[2].x, d2);
-                        d3 = __builtin_fmaf(pp[3].x, qq[3].x, d3);
-                        d0 = __builtin_fmaf(pp[0].y, qq[0].y, d0);
-                        d1 = __builtin_fmaf(pp[1].y, qq[1].y, d1);
-                        d2 = __builtin_fmaf(pp[2].y, qq[2].y, d2);
-                        d3 = __builtin_fmaf(pp[3].y, qq[3].y, d3);
-                        d0 = __builtin_fmaf(pp[0].z, qq[0].z, d0);
-                        d1 = __builtin_fmaf(pp[1].z, qq[1].z, d1);
-                        d2 = __builtin_fmaf(pp[2].z, qq[2].z, d2);
-                        d3 = __builtin_fmaf(pp[3].z, qq[3].z, d3);
-                        d0 = __builtin_fmaf(pp[0].w, qq[0].w, d0);
-                        d1 = __builtin_fmaf(pp[1].w, qq[1].w, d1);
-                        d2 = __builtin_fmaf(pp[2].w, qq[2].w, d2);
-                        d3 = __builtin_fmaf(pp[3].w, qq[3].w, d3);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                d = (d0 + d1) + (d2 + d3);
+            for (int i = 0; i < SW; ++i) {
+                pv[i] = lds4(prow + min(w * SW + i, nslots - 1));
+                qv[i] = lds4(qrow + w * SW + i);
             }
-            if (m == 8) stamp.mark(it, 1);
-            // (B) e = M rhs
+            f32x2 dacc[2] = {dup2(0.f), dup2(0.f)};
+            if (!(CU2REC_BS_ABLATE & 8)) {
+#pragma unroll
+                for (int i = 0; i < SW; ++i) {
+                    dacc[0] = fma2(lo2(pv[i]), lo2(qv[i]), dacc[0]);
+                    dacc[1] = fma2(hi2(pv[i]), hi2(qv[i]), dacc[1]);
+                }
+            }
+            const f32x2 ds = dacc[0] + dacc[1];
+            reinterpret_cast<float *>(dpart)[4 * k + w] = ds.x + ds.y;
+        }
+        met += 4;
+        solvers_meet(meet, met, k);
+        if (live) {
+            // (B) e = M rhs: 16 columns each
+            const f32x4 d4 = lds4(dpart + k);
+            const float d = (d4.x + d4.y) + (d4.z + d4.w);
             const float rhs = k < n ? (base - (b - cdel_k * b)) - (d - adel_k * d) : 0.f;
             rbuf[k] = rhs;
             __builtin_amdgcn_wave_barrier();
-            float e = 0.f;
-            {
-                const float4 *rv = reinterpret_cast<const float4 *>(rbuf);
+            const float4 *rv = reinterpret_cast<const float4 *>(rbuf) + 4 * w;
+            f32x2 eacc[2] = {dup2(0.f), dup2(0.f)};
+            if (!(CU2REC_BS_ABLATE & 16)) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float4 r0 = rv[t], r1 = rv[8 + t];
-                    e = __builtin_fmaf(ma[t].x, r0.x, e);
-                    e = __builtin_fmaf(ma[t].y, r0.y, e);
-                    e = __builtin_fmaf(ma[t].z, r0.z, e);
-                    e = __builtin_fmaf(ma[t].w, r0.w, e);
-                    e = __builtin_fmaf(mb[t].x, r1.x, e);
-                    e = __builtin_fmaf(mb[t].y, r1.y, e);
-                    e = __builtin_fmaf(mb[t].z, r1.z, e);
-                    e = __builtin_fmaf(mb[t].w, r1.w, e);
+                for (int t = 0; t < 4; ++t) {
+                    const f32x4 r4 = lds4(rv + t);
+                    eacc[0] = fma2(lo2(mq[t]), lo2(r4), eacc[0]);
+                    eacc[1] = fma2(hi2(mq[t]), hi2(r4), eacc[1]);
                 }
             }
-            if (m == 8) stamp.mark(it, 2);
-            if (k < n) it.ebuf[begin + kB * m + k] = e;
+            const f32x2 es = eacc[0] + eacc[1];
+            reinterpret_cast<float *>(epart)[4 * k + w] = es.x + es.y;
+        }
+        met += 4;
+        solvers_meet(meet, met, k);
+        if (live) {
+            const f32x4 e4 = lds4(epart + k);
+            const float e = (e4.x + e4.y) + (e4.z + e4.w);
+            if (!(CU2REC_BS_ABLATE & 1) && w == 0 && k < n) it.ebuf[begin + kB * m + k] = e;
             // (C) the state the block leaves behind; its start state goes to phase 3
             wbuf[k] = k < n ? lr * apr * e : 0.f;
             const float bs = row_sum16(k < n ? lr * cpr * e : 0.f);
             b = (b - cdel_n * b) + ((lane_value(bs, 0) + lane_value(bs, 16)) + (lane_value(bs, 32) + lane_value(bs, 48)));
             __builtin_amdgcn_wave_barrier();
-            float4 *qdst = reinterpret_cast<float4 *>(it.qstart + static_cast<size_t>(g0 + m) * a.ldq);
+            f32x4 *qdst = reinterpret_cast<f32x4 *>(it.qstart + static_cast<size_t>(g0 + m) * a.ldq);
+            const float4 *wv = reinterpret_cast<const float4 *>(wbuf) + 2 * kg;
 #pragma unroll
-            for (int p = 0; p < NPS; ++p) {  // lane (slot, half): sum over the half's 32 links of w_k P[k][slot]
-                const int slot = 32 * p + sl;
-                const bool ok = slot < nslots;
-                if (ok && kp == 0) qdst[slot] = q4[p];
-                const float4 *colp = tile + (kH * kp) * RS + min(slot, nslots - 1);
-                const float4 *wv = reinterpret_cast<const float4 *>(wbuf + kH * kp);
-                float4 tb[2][16], wb[2][4];  // all 32 rows of the half requested before the first product
+            for (int p = 0; p < NP; ++p) {  // lane (slot, group): sum over the group's 8 links of w_k P[k][slot]
+                const int sq = 8 * p + sl, slot = w * SW + sq;
+                const bool ok = sq < SW && slot < nslots;
+                if (!(CU2REC_BS_ABLATE & 1) && ok && kg == 0) qdst[slot] = q4[p];
+                const float4 *colp = tile + (8 * kg) * RS + min(slot, nslots - 1);
+                f32x4 tb[8], wb[2];
 #pragma unroll
-                for (int gq = 0; gq < 2; ++gq) {
+                for (int i = 0; i < 8; ++i) tb[i] = lds4(colp + i * RS);
+                wb[0] = lds4(wv), wb[1] = lds4(wv + 1);
+                f32x2 ulo = dup2(0.f), uhi = dup2(0.f);
+                if (!(CU2REC_BS_ABLATE & 2)) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) tb[gq][i] = colp[(16 * gq + i) * RS];
-#pragma unroll
-                    for (int t4 = 0; t4 < 4; ++t4) wb[gq][t4] = wv[4 * gq + t4];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                float4 u = zero4();
-#pragma unroll
-                for (int gq = 0; gq < 2; ++gq) {
-#pragma unroll
-                    for (int t4 = 0; t4 < 4; ++t4) {
-                        const float wl[4] = {wb[gq][t4].x, wb[gq][t4].y, wb[gq][t4].z, wb[gq][t4].w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float4 p4 = tb[gq][4 * t4 + i];
-                            u.x = __builtin_fmaf(wl[i], p4.x, u.x);
-                            u.y = __builtin_fmaf(wl[i], p4.y, u.y);
-                            u.z = __builtin_fmaf(wl[i], p4.z, u.z);
-                            u.w = __builtin_fmaf(wl[i], p4.w, u.w);
-                        }
+                    for (int i = 0; i < 8; ++i) {
+                        const f32x2 ww = dup2(wb[i >> 2][i & 3]);
+                        ulo = fma2(ww, lo2(tb[i]), ulo);
+                        uhi = fma2(ww, hi2(tb[i]), uhi);
                     }
                 }
-                u = make_float4(half_sum(u.x), half_sum(u.y), half_sum(u.z), half_sum(u.w));
-                const float4 qo = q4[p];
-                q4[p] = ok ? make_float4((qo.x - adel_n * qo.x) + u.x, (qo.y - adel_n * qo.y) + u.y,
-                                         (qo.z - adel_n * qo.z) + u.z, (qo.w - adel_n * qo.w) + u.w)
-                           : zero4();
-                if (kp == 0 && slot < 4 * SW + 8) qrow[slot] = q4[p];
+                float u[4] = {ulo.x, ulo.y, uhi.x, uhi.y};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {  // the eight groups: lanes l ^ 8, l ^ 16, l ^ 32
+                    u[c] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u[c]), 0x128, 0xf, 0xf, false));  // row_ror:8
+                    u[c] = half_sum(row_pair_sum(u[c]));
+                }
+                const f32x4 qo = q4[p];
+                q4[p] = ok ? f32x4{(qo.x - adel_n * qo.x) + u[0], (qo.y - adel_n * qo.y) + u[1], (qo.z - adel_n * qo.z) + u[2],
+                                   (qo.w - adel_n * qo.w) + u[3]}
+                           : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kg == 0 && sq < SW) *reinterpret_cast<f32x4 *>(qrow + slot) = q4[p];
             }
-            if (m == 8) stamp.mark(it, 3);
         }
         __syncthreads();
     }
-    if (kp == 0) {
-        float4 *qdst = reinterpret_cast<float4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
+    if (kg == 0) {
+        f32x4 *qdst = reinterpret_cast<f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
 #pragma unroll
-        for (int p = 0; p < NPS; ++p)
-            if (32 * p + sl < nslots) qdst[32 * p + sl] = q4[p];
+        for (int p = 0; p < NP; ++p) {
+            const int sq = 8 * p + sl, slot = w * SW + sq;
+            if (sq < SW && slot < nslots) qdst[slot] = q4[p];
+        }
     }
-    if (k == 0) a.item_bias[y] = b;
-    stamp.done(it, 2, static_cast<int>(blockIdx.x) * 4);
+    if (tid == 0) a.item_bias[y] = b;
+    stamp.done(it, 2, static_cast<int>(blockIdx.x) * 4 + w);
 }
 
 // ---- phase 3: the user side of every hot block ---------------------------------------------------------------------
@@ -646,21 +961,22 @@ __global__ __launch_bounds__(256) void bs_solve_kernel(SgdArgs a, BsIteration it
 // operand and the old value of the update, takes the new values and leaves with eight 16-byte stores per lane; errors,
 // user ids and the powers of a are read from LDS as well (a lane-dependent readlane would turn into branches).
 constexpr int kUpdStride = 36;                               // floats per tile row: 16-byte rows, 2-way conflicts at most
-constexpr int kUpdWaveFloats = kB * kUpdStride + 2 * kB;     // tile | e | user ids
+constexpr int kUpdWaveFloats = kB * kUpdStride + 3 * kB;     // tile | e | user ids | partial errors (affine blocks)
 constexpr int kUpdPowPad = 32;                               // a^d, d in [-32, 64), zero below 0
-__global__ __launch_bounds__(256) void bs_update_kernel(SgdArgs a, BsIteration it, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float upd_smem[4 * kUpdWaveFloats + kUpdPowPad + kB];
+__host__ __device__ inline size_t update_lds_bytes(int ntiles) { return (static_cast<size_t>(ntiles) * kUpdWaveFloats + kUpdPowPad + kB) * 4; }
+
+// One workgroup per block, one wavefront per 32 columns.
+__global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration it, int ntiles) {
+    extern __shared__ float4 bs_smem[];
+    float *upd_smem = reinterpret_cast<float *>(bs_smem);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *pw = upd_smem + 4 * kUpdWaveFloats;
-    if (threadIdx.x < kUpdPowPad + kB)
-        pw[threadIdx.x] = threadIdx.x < kUpdPowPad ? 0.f : it.tables[kTabApow + threadIdx.x - kUpdPowPad];
-    __syncthreads();
-    const int unit = blockIdx.x * 4 + wave;
-    const int g = unit / ntiles, ct = unit - g * ntiles;
-    if (g >= it.max_blocks) return;
+    float *pw = upd_smem + ntiles * kUpdWaveFloats;
+    const int g = blockIdx.x, ct = wave;
     WaveStamp stamp(it);
     const BsBlockDesc bd = it.blocks[g];
-    if (bd.n_valid == 0) return;
+    if (bd.n_valid == 0) return;  // workgroup uniform
+    const bool affine = block_is_affine(it, bd);
+    for (int i = threadIdx.x; i < kUpdPowPad + kB; i += blockDim.x) pw[i] = i < kUpdPowPad ? 0.f : it.tables[kTabApow + i - kUpdPowPad];
     float *tile = upd_smem + wave * kUpdWaveFloats;
     float *se = tile + kB * kUpdStride;
     int *sx = reinterpret_cast<int *>(se + kB);
@@ -669,14 +985,41 @@ __global__ __launch_bounds__(256) void bs_update_kernel(SgdArgs a, BsIteration i
     // links past the end of a short block: the last link's row (finite, loaded, never stored) with e = 0
     const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
     const int x = static_cast<int>(val >> 32);
-    const float e_all = it.ebuf[bd.pos0 + min(lane, bd.n_valid - 1)];
-    const float e = mine ? e_all : 0.f;
-    se[lane] = e;
-    sx[lane] = x;
     const float lr = a.h.lr;
     const int ncols = 4 * a.nslots;
     const int col = 32 * ct + c, colc = min(col, ncols - 1);
     const float qs = it.qstart[static_cast<size_t>(g) * a.ldq + colc];
+    float e_all;
+    if (affine) {
+        // e = -W (s0, -1): lane = link, this wavefront's share of the 16-byte columns, the shares summed through LDS
+        const int nslots = a.nslots, n4 = (nslots + 1) | 1;
+        const float4 *wrow = reinterpret_cast<const float4 *>(it.Wbuf + static_cast<size_t>(g) * bs_affine_w_floats(nslots)) + lane * n4;
+        const float4 *q4 = reinterpret_cast<const float4 *>(it.qstart + static_cast<size_t>(g) * a.ldq);
+        const float b0 = it.bstart[g];
+        float part = 0.f;
+        for (int cc = ct; cc <= nslots; cc += ntiles) {
+            const float4 w4 = wrow[cc];
+            const float4 qv = q4[min(cc, nslots - 1)];
+            const float4 sv = cc < nslots ? qv : make_float4(b0, -1.f, 0.f, 0.f);
+            part = __builtin_fmaf(w4.x, sv.x, part);
+            part = __builtin_fmaf(w4.y, sv.y, part);
+            part = __builtin_fmaf(w4.z, sv.z, part);
+            part = __builtin_fmaf(w4.w, sv.w, part);
+        }
+        float *parts = upd_smem + ct * kUpdWaveFloats + kB * kUpdStride + 2 * kB;
+        parts[lane] = part;
+        __syncthreads();
+        float sum = 0.f;
+        for (int w = 0; w < ntiles; ++w) sum += upd_smem[w * kUpdWaveFloats + kB * kUpdStride + 2 * kB + lane];
+        e_all = -sum;
+        if (ct == 0 && mine) it.ebuf[bd.pos0 + lane] = e_all;  // for the record (tests read the errors back)
+    } else {
+        e_all = it.ebuf[bd.pos0 + min(lane, bd.n_valid - 1)];
+        __syncthreads();  // the table of powers
+    }
+    const float e = mine ? e_all : 0.f;
+    se[lane] = e;
+    sx[lane] = x;
     __builtin_amdgcn_wave_barrier();
     const int rsub = lane >> 3, cs = lane & 7;
     const int slot = 8 * ct + cs, slotc = min(slot, a.nslots - 1);
@@ -750,19 +1093,21 @@ __global__ __launch_bounds__(256) void bs_update_kernel(SgdArgs a, BsIteration i
         const float ub = a.user_bias[x];
         a.user_bias[x] = ub + lr * (e - a.h.ub_reg * ub);  // mf_sequential.cu:140
     }
-    stamp.done(it, 4, unit);
+    stamp.done(it, 4, g * ntiles + ct);
 }
 
 template <int SW>
 void launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
-    const size_t lds = solve_lds_bytes(a.nslots, SW);
+    const size_t lds = std::max(solve_lds_bytes(a.nslots, SW), it.aff_min_blocks > 0 ? affine_lds_bytes(a.nslots) : static_cast<size_t>(0));
     static bool attr_set = false;  // one per instantiation
     if (!attr_set) {
         CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bs_solve_kernel<SW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(bs_solve_kernel<SW>, dim3(it.n_hot), dim3(256), lds, stream, a, it);
+    const int helpers = it.pf_helpers > 0 ? 8 * it.pf_helpers * it.pf_chains : 0;
+    const int grid = helpers > 0 ? ((it.n_hot + 7) & ~7) + helpers : it.n_hot;
+    hipLaunchKernelGGL(bs_solve_kernel<SW>, dim3(grid), dim3(512), lds, stream, a, it);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
         fail(CU2REC_EHIP, std::string("bs_solve_kernel launch failed: ") + hipGetErrorString(err) + " (SW " + std::to_string(SW) +
@@ -801,7 +1146,8 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
-    const size_t gram_lds = static_cast<size_t>(kB) * (a.nslots | 1) * 16 + (static_cast<size_t>(5) * kH * kMS + kGramTabFloats) * 4;
+    const size_t gram_lds = static_cast<size_t>(kB) * (a.nslots | 1) * 16 +
+                            (static_cast<size_t>(5) * kH * kMS + (bs_affine_supported(a.nslots) ? kGramExtFloats : 0) + kGramTabFloats + kB) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bs_gram_kernel),
@@ -828,8 +1174,14 @@ void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream
 void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
     const int ntiles = (4 * a.nslots + 31) / 32;
-    const long units = static_cast<long>(it.max_blocks) * ntiles;
-    hipLaunchKernelGGL(bs_update_kernel, dim3(static_cast<unsigned>((units + 3) / 4)), dim3(256), 0, stream, a, it, ntiles);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bs_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bs_update_kernel, dim3(it.max_blocks), dim3(64 * ntiles), update_lds_bytes(ntiles), stream, a, it, ntiles);
+    CU2REC_HIP(hipGetLastError());
 }
 
 }  // namespace cu2rec

@@ -549,6 +549,8 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
 
 float cu2rec_blocksolve_min_rate(float rate) { return blocksolve_min_rate(rate); }
 
+int cu2rec_blocksolve_affine_blocks(int blocks) { return blocksolve_affine_blocks(blocks); }
+
 int cu2rec_debug_blocksolve_stamps(void *buffer, int capacity) {
     return guarded([&] {
         require(capacity >= 0, "cu2rec_debug_blocksolve_stamps: bad capacity");

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <vector>
@@ -47,7 +48,7 @@ namespace {
 
 using namespace dev;
 
-constexpr int kWindow = 4;     // sorted positions per group (regular chains)
+constexpr int kWindow = 1;     // sorted positions per group (regular chains)
 constexpr int kHotChains = 256;  // most popular items: their chains run in the two-wave form (run_hot_block_duo)
 
 __global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__restrict__ indptr,
@@ -422,22 +423,62 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
         const int y = item_of_rank[key & item_mask];
         Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
         float ib = a.item_bias[y];
-        int s = start;
-        uint64_t val = vals[s];
-        bool more;
-        do {
-            const int x = static_cast<int>(val >> 32);
-            const float rating = __uint_as_float(static_cast<uint32_t>(val));
-            Row<J> p = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
-            const float ub = a.user_bias[x];
-            // look ahead while the row is in flight
-            ++s;
-            more = s < n_active && keys[s] == key;
-            if (more) val = vals[s];
-            const float new_ub = chain_step<J>(a, p, q, ub, ib, rating);
-            store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, p);
-            if (lane == 0) a.user_bias[x] = new_ub;
-        } while (more);
+        // the chain's length: the group looks at 16 keys at a time
+        const int gshift = threadIdx.x & 48;  // this group's bits in the wavefront's ballot
+        int len = 1;
+        for (;;) {
+            const int pos = start + len + lane;
+            const bool same = pos < n_active && keys[pos] == key;
+            const uint32_t m = static_cast<uint32_t>(__ballot(same) >> gshift) & 0xffffu;
+            const int run = __ffs(static_cast<int>(~m)) - 1;  // leading run of equal keys, 0..16
+            len += run;
+            if (run < 16) break;
+        }
+        // A chain is a string of dependent updates on the item row, but the users' rows are independent of it: they are
+        // fetched four links ahead (a walk that asks for a row only when it needs it pays the full memory latency per
+        // link, and the longest such chain -- some 25 links at a dozen expected updates -- was the whole launch).  Loads
+        // past the end of the chain re-read its last row (a cache hit) instead of being predicated.
+        for (int wb = 0; wb < len; wb += kGroup) {
+            const int nw = min(kGroup, len - wb);
+            const uint64_t myval = vals[start + wb + min(lane, nw - 1)];
+            auto link = [&](int i) -> uint64_t {
+                const int src = gshift + min(i, nw - 1);
+                const uint32_t lo = __shfl(static_cast<uint32_t>(myval), src), hi = __shfl(static_cast<uint32_t>(myval >> 32), src);
+                return static_cast<uint64_t>(hi) << 32 | lo;
+            };
+            constexpr int D = 4;
+            Row<J> cur[D], nxt[D];
+            float cub[D], nub[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int x = static_cast<int>(link(d) >> 32);
+                cur[d] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+                cub[d] = a.user_bias[x];
+            }
+            for (int b0 = 0; b0 < nw; b0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int x = static_cast<int>(link(b0 + D + d) >> 32);
+                    nxt[d] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+                    nub[d] = a.user_bias[x];
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    if (b0 + d < nw) {
+                        const uint64_t val = link(b0 + d);
+                        const int x = static_cast<int>(val >> 32);
+                        const float new_ub = chain_step<J>(a, cur[d], q, cub[d], ib, __uint_as_float(static_cast<uint32_t>(val)));
+                        store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, cur[d]);
+                        if (lane == 0) a.user_bias[x] = new_ub;
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    cur[d] = nxt[d];
+                    cub[d] = nub[d];
+                }
+            }
+        }
         store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
         if (lane == 0) a.item_bias[y] = ib;
     }
@@ -582,10 +623,26 @@ float blocksolve_min_rate(float rate) {
     return prev;
 }
 
+namespace {
+std::atomic<int> g_bs_affine_blocks{-1};
+}
+
+int blocksolve_affine_blocks(int blocks) {
+    int prev = g_bs_affine_blocks.load();
+    if (prev < 0) {  // first use: off (measured slower than the plain form), CU2REC_BLOCKSOLVE_AFFINE overrides
+        int init = 0;
+        if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_AFFINE")) init = std::max(0, std::atoi(env));
+        g_bs_affine_blocks.compare_exchange_strong(prev, init);
+        prev = g_bs_affine_blocks.load();
+    }
+    if (blocks >= 0) g_bs_affine_blocks.store(blocks);
+    return prev;
+}
+
 void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream, bool blocksolve) {
     if (n_active == 0) return;
     if (blocksolve) {
-        if (!bs_supported(a.nslots)) fail(CU2REC_EUNSUPPORTED, "block-solve mode is compiled for n_factors <= 256");
+        if (!bs_supported(a.nslots)) fail(CU2REC_EUNSUPPORTED, "block-solve mode is compiled for n_factors <= 252");
         const bool same = tables_valid && tables_for.lr == a.h.lr && tables_for.q_reg == a.h.q_reg && tables_for.ib_reg == a.h.ib_reg;
         if (!same) {  // stream ordered: kernels already queued keep the old tables
             bs_launch_tables(a.h, tables.ptr, stream);
@@ -596,6 +653,21 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             CU2REC_HIP(hipStreamSynchronize(stream));
             qstart.allocate(static_cast<size_t>(max_blocks) * a.ldq);
             qstart_ld = a.ldq;
+        }
+        aff_min_blocks = bs_affine_supported(a.nslots) ? blocksolve_affine_blocks(-1) : 0;
+        pf_helpers = 0, pf_chains = 0;  // measured: no gain (the loaders are not what bounds a chain), DESIGN.md section 4
+        if (const char *env = std::getenv("CU2REC_BS_PREFETCH")) {  // "helpers,chains": tuning aid
+            if (std::sscanf(env, "%d,%d", &pf_helpers, &pf_chains) != 2) pf_helpers = pf_chains = 0;
+            pf_helpers = std::max(0, std::min(pf_helpers, 16));
+            pf_chains = std::max(0, std::min(pf_chains, 8));
+            if (pf_chains == 0) pf_helpers = 0;
+        }
+        if (n_hot_bs > 0 && aff_min_blocks > 0 && affine_nslots != a.nslots) {
+            CU2REC_HIP(hipStreamSynchronize(stream));
+            Tbuf.allocate(static_cast<size_t>(max_blocks) * bs_affine_t_floats(a.nslots));
+            Wbuf.allocate(static_cast<size_t>(max_blocks) * bs_affine_w_floats(a.nslots));
+            bstart.allocate(max_blocks);
+            affine_nslots = a.nslots;
         }
         if (!side) {
             // The chains solved block-wise are the iteration's critical path; what runs beside them gets the lowest
@@ -700,6 +772,12 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.ebuf = ebuf.ptr;
                 it.qstart = qstart.ptr;
                 it.max_blocks = max_blocks;
+                it.aff_min_blocks = aff_min_blocks;
+                it.pf_helpers = pf_helpers;
+                it.pf_chains = pf_chains;
+                it.Tbuf = Tbuf.ptr;
+                it.Wbuf = Wbuf.ptr;
+                it.bstart = bstart.ptr;
                 bs_get_stamps(&it.stamps, &it.stamps_cap);
                 // The other chains touch other items and other users than the hot ones: fork, run beside, join.  The fork
                 // sits behind phase 1 and the chains' launch comes first: workgroups of the side kernel that already

@@ -60,6 +60,10 @@ struct OrderedSchedule {
     DeviceBuffer<BsChainDesc> bs_chains[2];
     DeviceBuffer<BsBlockDesc> bs_blocks[2];
     DeviceBuffer<float> tables, Mbuf, basebuf, ebuf, qstart;
+    DeviceBuffer<float> Tbuf, Wbuf, bstart;  // affine form of the long chains (blocksolve.hip); sized on first use
+    int affine_nslots = 0;
+    int aff_min_blocks = 0;  // of the run in progress
+    int pf_helpers = 0, pf_chains = 0;
     hipStream_t side = nullptr;            // the walked chains of an iteration run beside its three phases
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ~OrderedSchedule();
@@ -67,5 +71,7 @@ struct OrderedSchedule {
 
 // minimum expected updates per iteration of an item for block-wise treatment (process-wide; schedules created later)
 float blocksolve_min_rate(float rate);
+// chains of at least this many blocks of 64 links take the affine form (0: none); blocks < 0 only queries
+int blocksolve_affine_blocks(int blocks);
 
 }  // namespace cu2rec

@@ -169,7 +169,7 @@ typedef enum cu2rec_sgd_mode {
      * the solution of a unit lower triangular system built from the Gram matrix of the 32 user rows (matrix cores), a
      * scalar forward substitution replaces 32 dependent row updates (cu2rec_amd/csrc/blocksolve.hip).  Equal to the
      * sequential result up to float rounding (sums are associated differently), NOT bit for bit: tests pin it at
-     * |test RMSE - oracle| <= 1e-4 after 1,000 iterations of the ML-20M shape.  n_factors <= 256.  Needs a
+     * |test RMSE - oracle| <= 1e-4 after 1,000 iterations of the ML-20M shape.  n_factors <= 252.  Needs a
      * cu2rec_schedule like CU2REC_SGD_ORDERED. */
     CU2REC_SGD_BLOCKSOLVE = 4
 } cu2rec_sgd_mode;
@@ -273,6 +273,13 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
  * update.  Process-wide, read when a schedule is created; default 320 (CU2REC_BLOCKSOLVE_RATE in the environment
  * overrides).  Returns the previous value; rate <= 0 only queries. */
 float cu2rec_blocksolve_min_rate(float rate);
+/* Chains of at least `blocks` blocks of 64 updates (one item, one iteration) are advanced in the affine form: phase 1
+ * also builds, per block, the matrix that maps the item's row and bias at the start of the block to those at its end,
+ * and the chain itself is one matrix-vector product per block (n_factors <= 124; wider rows keep the plain form).
+ * Process-wide, read at every SGD call; default 0 = off: on MI355X the form measured slower than the plain one (one CU
+ * streams a 43 KB matrix per block at about 15 GB/s); CU2REC_BLOCKSOLVE_AFFINE overrides.
+ * Returns the previous value; blocks < 0 only queries. */
+int cu2rec_blocksolve_affine_blocks(int blocks);
 /* Development aid: while `buffer` (device memory, 8 * (1 + 8 * capacity) bytes, zeroed by the caller) is set, every
  * wavefront of the block-solve kernels writes {kernel, id, start, end, 4 marks (trace builds)} in ticks of the 100 MHz device clock into record
  * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 5 walk; records never written stay

@@ -49,7 +49,7 @@ def _max_diffs(model, state):
     (2000, 300, 40000, 64, 5, 0.5),
     (2000, 300, 40000, 128, 5, 0.5),
     (2000, 300, 40000, 200, 5, 0.5),  # 13 slots per column owner: the lane-per-column form of the transposed mat-vec
-    (2000, 300, 40000, 256, 3, 4.0),
+    (2000, 300, 40000, 252, 3, 4.0),
     (500, 50, 5000, 8, 10, 0.01),     # every item hot: nothing left for the walkers
     (9000, 6, 40000, 100, 3, 1.0),    # ~1,500 links per chain: the loader's ring (chains above six blocks)
 ])

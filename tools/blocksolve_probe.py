@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--factors", type=int, default=100)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--rate", type=float, default=0.0)
+    ap.add_argument("--affine", type=int, default=-1, help="chains of at least this many blocks take the affine form (0: off)")
     ap.add_argument("--skip-small", action="store_true")
     ap.add_argument("--skip-big", action="store_true")
     ap.add_argument("--stamps", action="store_true", help="wavefront timelines of one block-solve iteration")
@@ -28,11 +29,13 @@ def main():
     from oracle import oracle as orc
     import bench
     hyper = (0.01, 0.02, 0.02, 0.02, 0.02)
+    if args.affine >= 0:
+        api.blocksolve_affine_blocks(args.affine)
     if not args.skip_small:
         for users, items, nnz, f, iters, rate in ((300, 120, 6000, 10, 5, 2.0), (300, 120, 6000, 100, 70, 2.0),
                                                   (3000, 40, 30000, 100, 6, 1.0), (3000, 40, 30000, 50, 6, 1e9),
                                                   (2000, 300, 40000, 128, 5, 0.5), (2000, 300, 40000, 200, 5, 0.5),
-                                                  (2000, 300, 40000, 256, 3, 4.0), (500, 50, 5000, 8, 10, 0.01)):
+                                                  (2000, 300, 40000, 252, 3, 4.0), (500, 50, 5000, 8, 10, 0.01)):
             api.blocksolve_min_rate(rate)
             tr, te = synth.make_ratings(users, items, nnz, min_degree=3, seed=users + f)
             P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
@@ -66,9 +69,14 @@ def main():
         h = buf.cpu().numpy()
         rec = h[1:1 + 8 * cap].reshape(cap, 8)
         rec = rec[rec[:, 0] > 0]
+        xcc = rec[:, 0] >> 32
+        rec[:, 0] &= 0xffffffff
+        for kid, nm in ((2, "solver"), (6, "warm")):
+            sel = rec[:, 0] == kid
+            print("xcc of", nm, "records (id -> xcc):", [(int(i), int(x)) for i, x in zip(rec[sel, 1][:24], xcc[sel][:24])])
         n = len(rec)
         t_min = rec[:, 2].min()
-        names = {1: "gram", 2: "solver", 3: "loader", 4: "update", 5: "walk"}
+        names = {1: "gram", 2: "solver", 3: "loader", 4: "update", 5: "walk", 6: "warm"}
         print("stamps: %d wavefront records; times in us from the first start" % n)
         for kid in sorted(names):
             r = rec[rec[:, 0] == kid]
