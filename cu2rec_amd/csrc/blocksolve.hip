@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
     float *Ms = reinterpret_cast<float *>(bs_smem + gram_tile_float4s(nslots));  // M11 | M22
     float *Ns = Ms + 2 * kH * kMS;                                                // N00 (later M21) | N11 | N10
     float *Ws = Ns + kH * kMS;                // affine form: W [kB][kWS] takes over N11 | N10 and the extension behind
-    float *tab = Ms + 5 * kH * kMS + (bs_affine_supported(nslots) ? kGramExtFloats : 0);
+    float *tab = Ms + 5 * kH * kMS + (it.aff_min_blocks > 0 ? kGramExtFloats : 0);
     float *basev = tab + kGramTabFloats;      // [kB] r - gb - ub, 0 past the end of a short block
     const bool mine = lane < bd.n_valid;  // lane l: link l
     const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
@@ -1147,7 +1147,7 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
     const size_t gram_lds = static_cast<size_t>(kB) * (a.nslots | 1) * 16 +
-                            (static_cast<size_t>(5) * kH * kMS + (bs_affine_supported(a.nslots) ? kGramExtFloats : 0) + kGramTabFloats + kB) * 4;
+                            (static_cast<size_t>(5) * kH * kMS + (it.aff_min_blocks > 0 ? kGramExtFloats : 0) + kGramTabFloats + kB) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bs_gram_kernel),

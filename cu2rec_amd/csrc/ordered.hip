@@ -613,8 +613,8 @@ std::atomic<float> g_bs_min_rate{-1.f};
 
 float blocksolve_min_rate(float rate) {
     float prev = g_bs_min_rate.load();
-    if (prev < 0.f) {  // first use: default 320 expected updates per iteration, CU2REC_BLOCKSOLVE_RATE overrides
-        float init = 320.f;
+    if (prev < 0.f) {  // first use: default 240 expected updates per iteration, CU2REC_BLOCKSOLVE_RATE overrides
+        float init = 240.f;
         if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_RATE")) init = std::max(0.01f, static_cast<float>(std::atof(env)));
         g_bs_min_rate.compare_exchange_strong(prev, init);
         prev = g_bs_min_rate.load();
@@ -783,9 +783,16 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 // sits behind phase 1 and the chains' launch comes first: workgroups of the side kernel that already
                 // fill the CUs would keep the chains' workgroups (80 KB of LDS each) waiting, and those are the
                 // iteration's critical path (measured: the chains started 17 us late with the fork in front of phase 1).
+                static const bool fork_early = std::getenv("CU2REC_BS_FORK_EARLY") != nullptr;  // tuning aid
+                if (fork_early) {
+                    CU2REC_HIP(hipEventRecord(ev_fork, stream));
+                    CU2REC_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+                }
                 bs_launch_gram(a, it, stream);
-                CU2REC_HIP(hipEventRecord(ev_fork, stream));
-                CU2REC_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+                if (!fork_early) {
+                    CU2REC_HIP(hipEventRecord(ev_fork, stream));
+                    CU2REC_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+                }
                 bs_launch_solve(a, it, stream);
                 // ranks [n_hot_bs, n_duo_bs): the ordered mode's two-wave chains; beyond: its windowed walk
                 launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask,
