@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <limits>
 #include <numeric>
 #include <vector>
 
@@ -568,7 +569,16 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, dk, dv, static_cast<int>(cap), 0, 32, nullptr));
     temp.allocate(temp_bytes + 16);
     // block-solve workspace
-    const float min_rate = blocksolve_min_rate(-1.f);
+    // the threshold: what the caller set, else scaled with the set (a long chain costs the same whatever the set, the
+    // launch overhead it has to beat does not shrink with it; measured on 1/1 .. 1/8 of the ML-20M shape,
+    // profiles/r02_shard_size_probe_blocksolve.log)
+    float min_rate = blocksolve_min_rate(-1.f);
+    if (!blocksolve_min_rate_is_set()) {
+        min_rate = std::min(min_rate, std::max(30.f, min_rate * static_cast<float>(n_active) / 131072.f));
+        // no chain long enough to pay for three launches and two events per iteration: the ordered walk alone is faster
+        // (an eighth of the ML-20M shape, hottest item 247 updates per iteration: 40 against 53 us per iteration)
+        if (n_cols > 0 && rate[order[0]] < 350.0) min_rate = std::numeric_limits<float>::infinity();
+    }
     n_hot_bs = 0;
     while (n_hot_bs < n_cols && rate[order[n_hot_bs]] >= min_rate) ++n_hot_bs;
     n_hot_bs = std::min(n_hot_bs, (1 << item_bits) - 1);
@@ -609,17 +619,29 @@ OrderedSchedule::~OrderedSchedule() {
 
 namespace {
 std::atomic<float> g_bs_min_rate{-1.f};
+std::atomic<bool> g_bs_min_rate_set{false};
+}
+
+bool blocksolve_min_rate_is_set() {
+    (void)blocksolve_min_rate(-1.f);
+    return g_bs_min_rate_set.load();
 }
 
 float blocksolve_min_rate(float rate) {
     float prev = g_bs_min_rate.load();
     if (prev < 0.f) {  // first use: default 240 expected updates per iteration, CU2REC_BLOCKSOLVE_RATE overrides
         float init = 240.f;
-        if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_RATE")) init = std::max(0.01f, static_cast<float>(std::atof(env)));
+        if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_RATE")) {
+            init = std::max(0.01f, static_cast<float>(std::atof(env)));
+            g_bs_min_rate_set.store(true);
+        }
         g_bs_min_rate.compare_exchange_strong(prev, init);
         prev = g_bs_min_rate.load();
     }
-    if (rate > 0.f) g_bs_min_rate.store(rate);
+    if (rate > 0.f) {
+        g_bs_min_rate.store(rate);
+        g_bs_min_rate_set.store(true);
+    }
     return prev;
 }
 
@@ -641,6 +663,7 @@ int blocksolve_affine_blocks(int blocks) {
 
 void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream, bool blocksolve) {
     if (n_active == 0) return;
+    if (blocksolve && n_hot_bs == 0) blocksolve = false;  // nothing to solve block-wise: the ordered walk, bit for bit
     if (blocksolve) {
         if (!bs_supported(a.nslots)) fail(CU2REC_EUNSUPPORTED, "block-solve mode is compiled for n_factors <= 252");
         const bool same = tables_valid && tables_for.lr == a.h.lr && tables_for.q_reg == a.h.q_reg && tables_for.ib_reg == a.h.ib_reg;

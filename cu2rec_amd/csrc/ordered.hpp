@@ -71,6 +71,7 @@ struct OrderedSchedule {
 
 // minimum expected updates per iteration of an item for block-wise treatment (process-wide; schedules created later)
 float blocksolve_min_rate(float rate);
+bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwise a schedule scales the default with its set
 // chains of at least this many blocks of 64 links take the affine form (0: none); blocks < 0 only queries
 int blocksolve_affine_blocks(int blocks);
 
