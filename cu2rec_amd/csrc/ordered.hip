@@ -22,7 +22,8 @@
 //                        the iteration's critical path, so for ld <= 128 a block splits each chain over wavefronts:
 //                        a compute wave runs only the dependent arithmetic, two memory waves prefetch the users' rows,
 //                        publish them through LDS and apply / store the user-side updates (run_hot_block_duo).
-//        regular blocks  a 16-lane group owns a window of 4 sorted positions and runs every chain that STARTS there.
+//        regular blocks  a 16-lane group owns kWindow sorted positions and runs every chain that STARTS there, the
+//                        users' rows fetched four links ahead.
 // The arithmetic of one update is the same device code as the Hogwild kernel (sgd_device.hpp).
 #include <hip/hip_runtime.h>
 
