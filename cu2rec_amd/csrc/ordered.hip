@@ -50,7 +50,6 @@ namespace {
 
 using namespace dev;
 
-constexpr int kWindow = 1;     // sorted positions per group (regular chains)
 constexpr int kHotChains = 256;  // most popular items: their chains run in the two-wave form (run_hot_block_duo)
 
 __global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__restrict__ indptr,
@@ -397,118 +396,152 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     }
 }
 
+// A 16-lane group owns ONE sorted position and runs the chain that starts there (rank >= n_hot; longer chains have the
+// two-wave form).  A chain is a string of dependent updates on the item row, but nothing else about it depends on values:
+// three dependent round trips bring everything in -- (1) the 16 keys around the position and the 16 schedule entries
+// behind it, (2) the item's id and the first four users' rows, (3) the item row -- and the users' rows stay four links
+// ahead from there (a walk that asks for a row only when it needs it pays the memory latency per link).  Loads past the
+// end of the chain re-read its last row (a cache hit) instead of being predicated.
+template <int J>
+__device__ __forceinline__ void walk_group(const SgdArgs &a, const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
+                                           int n_active, const int *__restrict__ item_of_rank, uint32_t item_mask, int n_hot,
+                                           int start) {
+    constexpr int D = 4;
+    const int lane = threadIdx.x & (kGroup - 1);
+    const int gshift = threadIdx.x & 48;  // this group's lanes in the wavefront
+    if (start >= n_active) return;
+    const int kpos = start - 1 + lane;  // lane 0: the position in front, lane 1: this one, lanes 2..15: the next 14
+    const uint32_t key_l = keys[min(max(kpos, 0), n_active - 1)];
+    const uint64_t val0 = vals[min(start + lane, n_active - 1)];
+    const uint32_t key = __shfl(key_l, gshift + 1), prev = __shfl(key_l, gshift);
+    if (static_cast<int>(key & item_mask) < n_hot) return;  // a hot chain: the other role runs it
+    if (start > 0 && prev == key) return;                    // the chain began at an earlier position
+    const bool same0 = lane >= 2 && kpos < n_active && key_l == key;
+    const uint32_t m0 = (static_cast<uint32_t>(__ballot(same0) >> gshift) & 0xffffu) >> 2;  // bit i: keys[start + 1 + i] == key
+    int len = __ffs(static_cast<int>(~m0));  // 1 + leading run of equal keys: 1..15
+    bool more = len == 15;
+    auto link = [&](uint64_t mv, int i, int nw) -> uint64_t {
+        const int src = gshift + min(i, nw - 1);
+        const uint32_t lo = __shfl(static_cast<uint32_t>(mv), src), hi = __shfl(static_cast<uint32_t>(mv >> 32), src);
+        return static_cast<uint64_t>(hi) << 32 | lo;
+    };
+    Row<J> cur[D], nxt[D];
+    float cub[D], nub[D];
+    auto prime = [&](uint64_t mv, int nw) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int x = static_cast<int>(link(mv, d, nw) >> 32);
+            cur[d] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+            cub[d] = a.user_bias[x];
+        }
+    };
+    prime(val0, len);
+    const int y = item_of_rank[key & item_mask];
+    while (more) {  // the chain's length: the group looks at 16 more keys at a time
+        const int pos = start + len + lane;
+        const bool same = pos < n_active && keys[pos] == key;
+        const uint32_t m = static_cast<uint32_t>(__ballot(same) >> gshift) & 0xffffu;
+        const int run = __ffs(static_cast<int>(~m)) - 1;  // 0..16
+        len += run;
+        more = run == kGroup;
+    }
+    Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
+    float ib = a.item_bias[y];
+    for (int wb = 0; wb < len; wb += kGroup) {
+        const int nw = min(kGroup, len - wb);
+        uint64_t myval = val0;
+        if (wb > 0) {
+            myval = vals[start + wb + min(lane, nw - 1)];
+            prime(myval, nw);
+        }
+        for (int b0 = 0; b0 < nw; b0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int x = static_cast<int>(link(myval, b0 + D + d, nw) >> 32);
+                nxt[d] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+                nub[d] = a.user_bias[x];
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (b0 + d < nw) {
+                    const uint64_t val = link(myval, b0 + d, nw);
+                    const int x = static_cast<int>(val >> 32);
+                    const float new_ub = chain_step<J>(a, cur[d], q, cub[d], ib, __uint_as_float(static_cast<uint32_t>(val)));
+                    store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, cur[d]);
+                    if (lane == 0) a.user_bias[x] = new_ub;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                cur[d] = nxt[d];
+                cub[d] = nub[d];
+            }
+        }
+    }
+    store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
+    if (lane == 0) a.item_bias[y] = ib;
+}
+
 // One launch = one iteration.  Two roles, chosen per block:
 //  * blocks [0, hot_blocks): the chains of popularity ranks r < n_hot, DuoShape::kChains per block, in the two-wave
 //    form above.  These are the long chains (thousands of updates on the most rated items), i.e. the critical path.
-//  * the other blocks: a group owns a window of kWindow sorted positions and runs every chain of rank >= n_hot
-//    that STARTS in its window (chains are short there; one row of look-ahead).
+//  * the other blocks: walk_group, one sorted position per 16-lane group.
 template <int J>
 __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const uint32_t *__restrict__ keys,
                                                              const uint64_t *__restrict__ vals, int n_active,
                                                              const int *__restrict__ item_of_rank,
                                                              uint32_t item_mask, uint32_t key_base, int n_hot,
                                                              int hot_blocks, int rank_lo) {
-    const int lane = threadIdx.x & (kGroup - 1);
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
         // two-wave form for every row width: 32 lanes x 1 slot when 65 <= ld <= 128, else 16 lanes x J slots
         run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank, rank_lo);
         return;
     }
-    const int group = ((blockIdx.x - hot_blocks) * kBlock + threadIdx.x) / kGroup;
-    const int w0 = group * kWindow;
-    for (int t = 0; t < kWindow; ++t) {
-        const int start = w0 + t;
-        if (start >= n_active) break;
-        const uint32_t key = keys[start];
-        if (static_cast<int>(key & item_mask) < n_hot) continue;  // a hot chain: the other role runs it
-        if (start > 0 && keys[start - 1] == key) continue;        // the chain began in an earlier window
-        const int y = item_of_rank[key & item_mask];
-        Row<J> q = load_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane);
-        float ib = a.item_bias[y];
-        // the chain's length: the group looks at 16 keys at a time
-        const int gshift = threadIdx.x & 48;  // this group's bits in the wavefront's ballot
-        int len = 1;
-        for (;;) {
-            const int pos = start + len + lane;
-            const bool same = pos < n_active && keys[pos] == key;
-            const uint32_t m = static_cast<uint32_t>(__ballot(same) >> gshift) & 0xffffu;
-            const int run = __ffs(static_cast<int>(~m)) - 1;  // leading run of equal keys, 0..16
-            len += run;
-            if (run < 16) break;
-        }
-        // A chain is a string of dependent updates on the item row, but the users' rows are independent of it: they are
-        // fetched four links ahead (a walk that asks for a row only when it needs it pays the full memory latency per
-        // link, and the longest such chain -- some 25 links at a dozen expected updates -- was the whole launch).  Loads
-        // past the end of the chain re-read its last row (a cache hit) instead of being predicated.
-        for (int wb = 0; wb < len; wb += kGroup) {
-            const int nw = min(kGroup, len - wb);
-            const uint64_t myval = vals[start + wb + min(lane, nw - 1)];
-            auto link = [&](int i) -> uint64_t {
-                const int src = gshift + min(i, nw - 1);
-                const uint32_t lo = __shfl(static_cast<uint32_t>(myval), src), hi = __shfl(static_cast<uint32_t>(myval >> 32), src);
-                return static_cast<uint64_t>(hi) << 32 | lo;
-            };
-            constexpr int D = 4;
-            Row<J> cur[D], nxt[D];
-            float cub[D], nub[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int x = static_cast<int>(link(d) >> 32);
-                cur[d] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
-                cub[d] = a.user_bias[x];
-            }
-            for (int b0 = 0; b0 < nw; b0 += D) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const int x = static_cast<int>(link(b0 + D + d) >> 32);
-                    nxt[d] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
-                    nub[d] = a.user_bias[x];
-                }
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    if (b0 + d < nw) {
-                        const uint64_t val = link(b0 + d);
-                        const int x = static_cast<int>(val >> 32);
-                        const float new_ub = chain_step<J>(a, cur[d], q, cub[d], ib, __uint_as_float(static_cast<uint32_t>(val)));
-                        store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, cur[d]);
-                        if (lane == 0) a.user_bias[x] = new_ub;
-                    }
-                }
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    cur[d] = nxt[d];
-                    cub[d] = nub[d];
-                }
-            }
-        }
-        store_row<J>(a.Q, static_cast<size_t>(y), a.ldq, a.nslots, lane, q);
-        if (lane == 0) a.item_bias[y] = ib;
-    }
+    walk_group<J>(a, keys, vals, n_active, item_of_rank, item_mask, n_hot,
+                  static_cast<int>((blockIdx.x - hot_blocks) * kBlock + threadIdx.x) / kGroup);
 }
+
+// The walk alone (block-solve mode runs it beside the two-wave chains on a stream of its own: inside sgd_ordered_kernel
+// every block reserves the two-wave role's 33 KB of LDS, which halves the walk's occupancy).
+template <int J>
+__global__ __launch_bounds__(kBlock) void sgd_walk_kernel(SgdArgs a, const uint32_t *__restrict__ keys,
+                                                          const uint64_t *__restrict__ vals, int n_active,
+                                                          const int *__restrict__ item_of_rank, uint32_t item_mask, int n_hot) {
+    walk_group<J>(a, keys, vals, n_active, item_of_rank, item_mask, n_hot, static_cast<int>(blockIdx.x * kBlock + threadIdx.x) / kGroup);
+}
+
+// roles: kRoleDuo = the two-wave chains of ranks [rank_lo, n_hot), kRoleWalk = the walk of ranks >= n_hot; both in one launch
+// (the ordered mode), or one launch each (block-solve mode, two streams)
+constexpr int kRoleDuo = 1, kRoleWalk = 2;
 
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
-                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo = 0) {
-    // ranks [rank_lo, n_hot): the two-wave form; ranks >= n_hot: the windowed walk; ranks < rank_lo: not touched
+                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles) {
     const int chains_per_block = DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains;
     const int hot_blocks = (std::max(n_hot - rank_lo, 0) + chains_per_block - 1) / chains_per_block;
-    const int groups = (n_active + kWindow - 1) / kWindow;
-    const int blocks = hot_blocks + (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
+    const int walk_blocks = (n_active + kGroupsPerBlock - 1) / kGroupsPerBlock;
+    if (roles == kRoleWalk) {
+        hipLaunchKernelGGL(sgd_walk_kernel<J>, dim3(walk_blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active, item_of_rank,
+                           item_mask, n_hot);
+        return;
+    }
+    const int blocks = hot_blocks + ((roles & kRoleWalk) ? walk_blocks : 0);
+    if (blocks == 0) return;
     hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,
                        item_of_rank, item_mask, key_base, n_hot, hot_blocks, rank_lo);
 }
 
 void launch_chains(const SgdArgs &a, const uint32_t *kb, const uint64_t *vb, int n_active, const int *item_of_rank,
-                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo) {
+                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles = kRoleDuo | kRoleWalk) {
     switch (slots_per_lane(a.nslots)) {
-        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
-        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
-        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
-        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
-        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
-        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
-        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
-        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo); break;
+        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
+        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
+        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
+        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
+        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
+        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
+        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
+        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
         default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
     }
 }
@@ -570,12 +603,13 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, dk, dv, static_cast<int>(cap), 0, 32, nullptr));
     temp.allocate(temp_bytes + 16);
     // block-solve workspace
-    // the threshold: what the caller set, else scaled with the set (a long chain costs the same whatever the set, the
-    // launch overhead it has to beat does not shrink with it; measured on 1/1 .. 1/8 of the ML-20M shape,
-    // profiles/r02_shard_size_probe_blocksolve.log)
+    // the threshold: what the caller set, else scaled with the set -- down (a long chain costs the same whatever the set,
+    // the launch overhead it has to beat does not shrink with it; 1/1 .. 1/8 of the ML-20M shape,
+    // profiles/r02_shard_size_probe_blocksolve.log) and up (Netflix shape, 480,189 users: 290 us per iteration at 800
+    // against 353 at 240 -- the chains of several hundred hot items do not fit the CUs at once)
     float min_rate = blocksolve_min_rate(-1.f);
     if (!blocksolve_min_rate_is_set()) {
-        min_rate = std::min(min_rate, std::max(30.f, min_rate * static_cast<float>(n_active) / 131072.f));
+        min_rate = std::max(30.f, min_rate * static_cast<float>(n_active) / 131072.f);
         // no chain long enough to pay for three launches and two events per iteration: the ordered walk alone is faster
         // (an eighth of the ML-20M shape, hottest item 247 updates per iteration: 40 against 53 us per iteration)
         if (n_cols > 0 && rate[order[0]] < 350.0) min_rate = std::numeric_limits<float>::infinity();
@@ -614,6 +648,8 @@ OrderedSchedule::~OrderedSchedule() {
         if (ev_consumed[slot]) (void)hipEventDestroy(ev_consumed[slot]);
     }
     if (side) (void)hipStreamDestroy(side);
+    if (side2) (void)hipStreamDestroy(side2);
+    if (ev_join2) (void)hipEventDestroy(ev_join2);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
 }
@@ -704,6 +740,11 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 (void)hipGetLastError();
                 CU2REC_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
             }
+            if (hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, lo) != hipSuccess) {
+                (void)hipGetLastError();
+                CU2REC_HIP(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
+            }
+            CU2REC_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
             CU2REC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
             CU2REC_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         }
@@ -819,11 +860,24 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 }
                 bs_launch_solve(a, it, stream);
                 // ranks [n_hot_bs, n_duo_bs): the ordered mode's two-wave chains; beyond: its windowed walk
-                launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask,
-                              static_cast<uint32_t>(b) << item_bits, std::max(n_duo_bs, n_hot_bs), side, n_hot_bs);
+                // (the walk as a launch of its own on a third stream -- inside sgd_ordered_kernel every block reserves the
+                // two-wave role's 33 KB of LDS -- was measured: both launches take ~50 us, the extra events cost 16 us)
+                static const bool split_walk = std::getenv("CU2REC_BS_SPLIT_WALK") != nullptr;  // tuning aid
+                if (split_walk) {
+                    CU2REC_HIP(hipStreamWaitEvent(side2, ev_fork, 0));
+                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask,
+                                  static_cast<uint32_t>(b) << item_bits, std::max(n_duo_bs, n_hot_bs), side, n_hot_bs, kRoleDuo);
+                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask,
+                                  static_cast<uint32_t>(b) << item_bits, std::max(n_duo_bs, n_hot_bs), side2, n_hot_bs, kRoleWalk);
+                    CU2REC_HIP(hipEventRecord(ev_join2, side2));
+                } else {
+                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask,
+                                  static_cast<uint32_t>(b) << item_bits, std::max(n_duo_bs, n_hot_bs), side, n_hot_bs);
+                }
                 CU2REC_HIP(hipEventRecord(ev_join, side));
                 bs_launch_update(a, it, stream);
                 CU2REC_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+                if (split_walk) CU2REC_HIP(hipStreamWaitEvent(stream, ev_join2, 0));
             }
             CU2REC_HIP(hipGetLastError());
             CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));

@@ -64,8 +64,9 @@ struct OrderedSchedule {
     int affine_nslots = 0;
     int aff_min_blocks = 0;  // of the run in progress
     int pf_helpers = 0, pf_chains = 0;
-    hipStream_t side = nullptr;            // the walked chains of an iteration run beside its three phases
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side = nullptr;            // the two-wave chains of an iteration run beside its three phases
+    hipStream_t side2 = nullptr;           // ... and so does the walk of the short chains, as a launch of its own
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     ~OrderedSchedule();
 };
 

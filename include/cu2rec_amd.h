@@ -270,10 +270,10 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
                                  void *stream);
 /* Which items CU2REC_SGD_BLOCKSOLVE solves block-wise: those expected to receive at least `rate` updates per
  * iteration (sum over the item's raters of 1 / the rater's number of ratings); the other chains are walked update by
- * update.  Process-wide, read when a schedule is created; default 240 for sets of 131,072 rating users and more, scaled
- * down with the set to no less than 30 (one GPU's shard of a strong-scaling run has shorter chains and the same launch
- * overheads); a value set here or by CU2REC_BLOCKSOLVE_RATE in the environment is taken as it is.  Returns the previous
- * value; rate <= 0 only queries. */
+ * update.  Process-wide, read when a schedule is created; default 240 per 131,072 rating users, scaled with the set (no
+ * less than 30: one GPU's shard of a strong-scaling run has shorter chains and the same launch overheads; the Netflix
+ * shape's 480,189 users give 880); a value set here or by CU2REC_BLOCKSOLVE_RATE in the environment is taken as it is.
+ * Returns the previous value; rate <= 0 only queries. */
 float cu2rec_blocksolve_min_rate(float rate);
 /* Chains of at least `blocks` blocks of 64 updates (one item, one iteration) are advanced in the affine form: phase 1
  * also builds, per block, the matrix that maps the item's row and bias at the start of the block to those at its end,
