@@ -292,7 +292,12 @@ def main():
     it += args.steps
     regions.append((first, first_dev))
     # a short region is mostly launch + synchronisation: repeat it and report the median (every region is exactly K steps)
-    n_regions = 1 if first >= 0.25 else 5
+    first_all = first
+    if world > 1:  # every rank must take the same decision: the regions are bracketed by barriers
+        t = torch.tensor([first], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        first_all = float(t.item())
+    n_regions = 1 if first_all >= 0.25 else 5
     for _ in range(n_regions - 1):
         regions.append(timed_region(it))
         it += args.steps
