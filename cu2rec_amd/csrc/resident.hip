@@ -68,6 +68,7 @@ using namespace dev;
 constexpr int kResBlock = 512;                    // 8 wavefronts = 2 per SIMD: up to 256 VGPRs each
 constexpr int kResGroups = kResBlock / kGroup;    // 32 user groups per workgroup
 constexpr unsigned long long kBarrierTimeoutTicks = 300000000ull;  // 3 s of the 100 MHz wall clock
+constexpr int kXcds = 8;                          // XCDs of an MI355X (single-XCD launches: cus / 8 workgroups run)
 
 // Barrier words, each on a 128-byte line of its own (indices into an array of unsigned, zeroed before every launch):
 constexpr int kLine = 32;
@@ -77,18 +78,21 @@ constexpr int kWCensusTop = kLine;                        // workgroups that hav
 constexpr int kWCensus = 2 * kLine;                       // [x]: workgroups on XCD x
 constexpr int kWArrive = kWCensus + kMaxXcc * kLine;      // [x]: arrivals on XCD x, summed over phases
 constexpr int kWGen = kWArrive + kMaxXcc * kLine;         // [x]: last phase XCD x may leave
-constexpr int kBarrierWords = kWGen + kMaxXcc * kLine;
+constexpr int kWTarget = kWGen + kMaxXcc * kLine;         // single-XCD launches: 1 + the XCD that runs them (workgroup 0's)
+constexpr int kBarrierWords = kWTarget + kLine;
 
 struct ResidentArgs {
     unsigned *words;       // the barrier block above (device memory)
     unsigned *status;      // set to 1 by a workgroup that gave up waiting (the host reads and clears it)
     float *sink;           // kSinkFloats floats nobody reads: where the updates of users without ratings are written
+    int local;             // 1: only the workgroups that share workgroup 0's XCD run (small sets: one L2, no write-back)
 };
 constexpr int kSinkBias = 512;                 // sink[0 .. 511]: an item row, sink[512]: an item bias
 constexpr int kSinkFloats = kSinkBias + 16;
 
 struct BarrierShared {  // per workgroup, in LDS; written by thread 0 only
     int xcc, n_mine, n_xcds, leader, ok;
+    int part, index;  // single-XCD launches: does this workgroup take part, and its number among those that do
 };
 
 __device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
@@ -119,7 +123,9 @@ __device__ __forceinline__ void barrier_census(const ResidentArgs &ra, BarrierSh
     // not overtake the first, which sits on another cache line), and a reader that has seen the full top count takes an
     // ACQUIRE before it reads the per-XCD counts.  With two relaxed adds a workgroup could see "everybody has arrived"
     // while the last per-XCD add was still in flight, undercount its XCD and open the barrier early.
-    __hip_atomic_fetch_add(ra.words + kWCensus + xcc * kLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned mine = __hip_atomic_fetch_add(ra.words + kWCensus + xcc * kLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ra.local && blockIdx.x == 0)  // (relaxed: ordered in front of the release below like the per-XCD count)
+        __hip_atomic_store(ra.words + kWTarget, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(ra.words + kWCensusTop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     bs->ok = spin_until(ra.words + kWCensusTop, gridDim.x, ra.status) ? 1 : 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -128,6 +134,12 @@ __device__ __forceinline__ void barrier_census(const ResidentArgs &ra, BarrierSh
     bs->xcc = static_cast<int>(xcc);
     bs->n_mine = static_cast<int>(ld_relaxed(ra.words + kWCensus + xcc * kLine));
     bs->n_xcds = n_xcds;
+    bs->part = 1;
+    bs->index = static_cast<int>(mine);
+    if (ra.local) {  // the barrier is that of ONE XCD from here on: its workgroups, numbered in the order they reported
+        bs->part = ld_relaxed(ra.words + kWTarget) == xcc + 1u ? 1 : 0;
+        bs->n_xcds = 1;
+    }
 }
 
 // Grid barrier, split in two so that work which does not depend on other workgroups (the next iteration's sample
@@ -143,8 +155,9 @@ __device__ __forceinline__ void barrier_arrive(const ResidentArgs &ra, unsigned 
                                                     __HIP_MEMORY_SCOPE_AGENT);
         const bool leader = old + 1 == phase * static_cast<unsigned>(bs->n_mine);
         if (leader) {
-            if (!(CU2REC_RES_ABLATE & 64))                          // 64: timing only, no L2 write-back
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines
+            if (!(CU2REC_RES_ABLATE & 64) && !ra.local)             // 64: timing only, no L2 write-back
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines (a single-XCD
+                                                                    // launch shares ONE L2: nothing to write back)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the compiler may drop its own wait here)
             __hip_atomic_fetch_add(ra.words + kWTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -253,8 +266,22 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
         for (int j = 0; j < J; ++j) my_lds[(rl * J + j) * kGroup] = row.v[j];
     };
     const int lane = threadIdx.x & (kGroup - 1);
-    const int group = blockIdx.x * kResGroups + (threadIdx.x / kGroup);
-    const int n_groups = gridDim.x * kResGroups;
+    int wg = blockIdx.x, n_wg = gridDim.x;
+    bool alive = true;
+    if (ra.local) {  // the census comes first: it says who runs and as which workgroup
+        if (threadIdx.x == 0) barrier_census(ra, &s_barrier);
+        __syncthreads();
+        if (!s_barrier.part) return;
+        alive = s_barrier.ok != 0;
+        wg = s_barrier.index;
+        n_wg = s_barrier.n_mine;
+        if (static_cast<long long>(n_wg) * kResGroups * R < a.n_rows) {  // fewer workgroups on this XCD than the host counted on
+            if (threadIdx.x == 0) __hip_atomic_store(ra.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    const int group = wg * kResGroups + (threadIdx.x / kGroup);
+    const int n_groups = n_wg * kResGroups;
 
     Slots<J> sl;
 #pragma unroll
@@ -318,8 +345,7 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
     float rating[M];
     draw(a.iter0, item, rating);
     const bool synced = !(CU2REC_RES_ABLATE & 1) && a.iters > 1;
-    bool alive = true;
-    if (synced) {
+    if (synced && !ra.local) {
         if (threadIdx.x == 0) barrier_census(ra, &s_barrier);
         __syncthreads();
         alive = s_barrier.ok != 0;  // false: the grid is not co-resident; nothing is run, the host reports it
@@ -513,13 +539,13 @@ int resident_policy(int set_to) {
         int from_env = kResidentAuto;
         if (const char *e = std::getenv("CU2REC_RESIDENT")) {
             const int v = std::atoi(e);
-            if (v >= kResidentOff && v <= kResidentForce) from_env = v;
+            if (v >= kResidentOff && v <= kResidentLocal) from_env = v;
         }
         int expected = -1;
         g_policy.compare_exchange_strong(expected, from_env);
     }
     const int prev = g_policy.load();
-    if (set_to >= kResidentOff && set_to <= kResidentForce) g_policy.store(set_to);
+    if (set_to >= kResidentOff && set_to <= kResidentLocal) g_policy.store(set_to);
     return prev;
 }
 
@@ -577,12 +603,24 @@ namespace {
 
 // The launch geometry a call would get, or false if it would stream.  Caller holds g_mutex.
 bool plan_locked(int n_rows, int nslots, int n_iters, int update_items, DeviceState *&state, int &variant, int &blocks,
-                 int &users_per_group) {
+                 int &users_per_group, bool &local) {
     const int policy = resident_policy(-1);
+    local = false;
     if (policy == kResidentOff || n_iters < 1 || n_rows < 1 || !update_items) return false;
     DeviceState &s = state_for_current_device();
     state = &s;
     int need = 0;
+    if (policy == kResidentLocal && s.cooperative && s.cus % kXcds == 0) {
+        // a set small enough for the CUs of ONE XCD: the whole grid is launched (one workgroup per CU, hence cus / 8 per
+        // XCD), the workgroups that share workgroup 0's XCD run
+        const long long groups = static_cast<long long>(s.cus / kXcds) * kResGroups;
+        const int need_local = static_cast<int>(std::min<long long>((n_rows + groups - 1) / groups, 1 << 20));
+        const int v = variant_for(slots_per_lane(nslots), need_local);
+        if (v >= 0 && s.usable[v]) {
+            variant = v, blocks = s.cus, users_per_group = kVariants[v].r, local = true;
+            return true;
+        }
+    }
     variant = geometry(n_rows, nslots, s.cus, need, blocks);
     if (variant < 0 || !s.usable[variant]) return false;  // the rows do not fit: stream them
     // Auto: the barrier costs a few microseconds where a kernel boundary costs one or two, so residency pays once
@@ -611,7 +649,9 @@ bool resident_plan(int n_rows, int n_factors, int n_iters, int *blocks_out, int 
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceState *s = nullptr;
     int variant = -1, blocks = 0, users_per_group = 0;
-    const bool yes = plan_locked(n_rows, (n_factors + 3) / 4, n_iters, 1, s, variant, blocks, users_per_group);
+    bool local = false;
+    const bool yes = plan_locked(n_rows, (n_factors + 3) / 4, n_iters, 1, s, variant, blocks, users_per_group, local);
+    if (yes && local) blocks = s->cus / kXcds;  // the workgroups that run
     if (blocks_out) *blocks_out = yes ? blocks : 0;
     if (users_per_group_out) *users_per_group_out = yes ? users_per_group : 0;
     return yes;
@@ -621,13 +661,14 @@ bool resident_launch(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream)
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceState *sp = nullptr;
     int variant = -1, blocks = 0, users_per_group = 0;
-    if (!plan_locked(a.n_rows, a.nslots, n_iters, a.update_items, sp, variant, blocks, users_per_group)) return false;
+    bool local = false;
+    if (!plan_locked(a.n_rows, a.nslots, n_iters, a.update_items, sp, variant, blocks, users_per_group, local)) return false;
     DeviceState &s = *sp;
 
     if (s.have_last && s.last_stream != stream) CU2REC_HIP(hipStreamWaitEvent(stream, s.done, 0));  // never two at once
     a.iter0 = iter0;
     a.iters = n_iters;
-    ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink};
+    ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink, local ? 1 : 0};
     void *args[] = {&a, &ra};
     CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));  // counters start from zero
     // A cooperative launch: the runtime checks the grid against what can be co-resident and REFUSES a larger one up

@@ -10,9 +10,10 @@
 
 namespace cu2rec {
 
-enum ResidentPolicy { kResidentOff = 0, kResidentAuto = 1, kResidentForce = 2 };
+// kResidentLocal: like Force, but a set that fits the CUs of ONE XCD runs there (one L2: a barrier without write-back)
+enum ResidentPolicy { kResidentOff = 0, kResidentAuto = 1, kResidentForce = 2, kResidentLocal = 3 };
 
-// Process-wide policy: CU2REC_RESIDENT=0|1|2 in the environment at first use, or cu2rec_hogwild_resident().
+// Process-wide policy: CU2REC_RESIDENT=0|1|2|3 in the environment at first use, or cu2rec_hogwild_resident().
 int resident_policy(int set_to /* < 0: query only */);
 
 // Runs iterations [iter0, iter0 + n_iters) of `a` (pointers, hyper-parameters, seed, user_offset filled in) in

@@ -225,8 +225,11 @@ int cu2rec_hogwild_iters_per_launch(int k);
  * kernel boundary, and every user's row stays in the register file for the whole call (no P traffic between
  * iterations).  Applies when all user rows of the CSR fit the register file + LDS (e.g. 204,000 users at f <= 128) and
  * hogwild_iters_per_launch is 1; otherwise the call runs one streaming launch per iteration as before.
- * policy: 0 never, 1 auto (default: when it fits and a call covers >= 4 iterations), 2 whenever it fits;
- * CU2REC_RESIDENT=0|1|2 in the environment sets the initial value.  Returns the previous policy; other values query.
+ * policy: 0 never, 1 auto (default: when it fits and a call covers >= 4 iterations), 2 whenever it fits, 3 like 2 but a set
+ * that fits the CUs of ONE XCD runs on those alone (the cooperative launch still covers the chip; the workgroups that share
+ * workgroup 0's XCD run, their barrier needs no L2 write-back -- measured slower than streaming on MI355X, one L2 being an
+ * eighth of the chip's bandwidth: profiles/r02_single_xcd_resident.log; kept for that measurement);
+ * CU2REC_RESIDENT=0|1|2|3 in the environment sets the initial value.  Returns the previous policy; other values query.
  * A resident launch assumes the GPU to itself (one workgroup per CU, all co-resident).  It is a cooperative launch: a
  * grid the runtime finds too large to be co-resident is refused up front and that call runs one streaming launch per
  * iteration instead (cu2rec_hogwild_resident_refusals counts them) -- nothing is lost.  What a launch-time check cannot
