@@ -185,3 +185,29 @@ def test_hogwild_gap_to_sequential_is_pinned_at_full_shape(policy, name):
         lib().cu2rec_hogwild_resident(prev)
     assert gaps[0] <= 8e-4 and gaps[1] <= 4e-3, (name, gaps)
     assert gaps[1] > 1e-4, (name, gaps)
+
+
+def test_bin_mf_blocksolve_mode_against_the_oracle_run(tmp_path):
+    """bin/mf -m blocksolve end to end (mf.cu:16-99): the printed TEST RMSE lines and the written factors against the
+    oracle's sequential run of the same schedule (CU2REC_BLOCKSOLVE_RATE makes half of the items hot on this small set)."""
+    import os
+    import re
+    import subprocess
+    from conftest import ROOT
+    tr, te = synth.make_ratings(3000, 60, 40000, min_degree=3, seed=31)
+    synth.write_csv(str(tmp_path / "train.csv"), tr)
+    synth.write_csv(str(tmp_path / "test.csv"), te)
+    (tmp_path / "c.cfg").write_text("0 40 16 0.01 42 0.02 0.02 0.02 0.02\n")
+    env = dict(os.environ, CU2REC_BLOCKSOLVE_RATE="1.0")
+    out = subprocess.run([os.path.join(ROOT, "bin", "mf"), "-c", str(tmp_path / "c.cfg"), "-m", "blocksolve", str(tmp_path / "train.csv"),
+                          str(tmp_path / "test.csv")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, 16)
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, 40, dot_order=orc.DOT_TREE16)
+    want_rmse = orc.loss(orc.CSR(te.indptr, te.indices, te.data, te.rows, te.cols, te.global_bias), P, Q, ub, ib, tr.global_bias,
+                         dot_order=orc.DOT_TREE16)["rmse"]
+    got_rmse = float(re.findall(r"TEST: Iteration 40 GPU MAE: \S+ RMSE: (\S+)", out.stdout)[-1])
+    assert abs(got_rmse - want_rmse) <= 2e-6
+    for comp, want in (("p", P), ("q", Q), ("user_bias", ub), ("item_bias", ib)):
+        got = np.loadtxt(str(tmp_path / ("train_f16_%s.csv" % comp)), delimiter=",", ndmin=2).reshape(want.shape)
+        assert float(np.abs(got - want).max()) <= 5e-6, comp  # %f files: six decimals
