@@ -211,3 +211,23 @@ def test_bin_mf_blocksolve_mode_against_the_oracle_run(tmp_path):
     for comp, want in (("p", P), ("q", Q), ("user_bias", ub), ("item_bias", ib)):
         got = np.loadtxt(str(tmp_path / ("train_f16_%s.csv" % comp)), delimiter=",", ndmin=2).reshape(want.shape)
         assert float(np.abs(got - want).max()) <= 5e-6, comp  # %f files: six decimals
+
+
+def test_train_in_blocksolve_mode_follows_the_oracle_schedule(min_rate):
+    """cu2rec_train (training.cu:95-180) with CU2REC_SGD_BLOCKSOLVE: same checks, same patience / decay decisions and learning
+    rate as the oracle's sequential run, logged test RMSE within float rounding of the re-associated sums."""
+    min_rate(1.0)
+    tr, te = synth.make_ratings(3000, 60, 40000, min_degree=3, seed=17)
+    kw = dict(total_iterations=48, n_factors=20, check_error=8, learning_rate=0.05, patience=1.0)
+    cfg, ocfg = cu.default_config(**kw), orc.default_config(**kw)
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, 20)
+    log = orc.train(_as_orc(tr), orc.CSR(te.indptr, te.indices, te.data, te.rows, te.cols, te.global_bias), ocfg, P, Q, ub, ib,
+                    tr.global_bias, dot_order=orc.DOT_TREE16, acc=orc.ACC_F64, schedule=orc.SCHED_PATIENCE)
+    gP, gQ, losses, gub, gib, stats = cu.train(tr, te, cfg, mode="blocksolve", verbose=False, return_stats=True)
+    assert [e["iteration"] - 1 for e in log] == [0, 7, 15, 23, 31, 39, 47]
+    for e in log:
+        assert abs(float(losses[e["iteration"] - 1]) - e["test_rmse"]) <= 2e-6
+    assert cfg.learning_rate == ocfg.learning_rate and cfg.cur_iterations == 48 == ocfg.cur_iterations
+    assert stats.n_checks == 7
+    for g, w in ((gP, P), (gQ, Q), (gub, ub), (gib, ib)):
+        assert float(np.abs(g.astype(np.float64) - w).max()) <= 5e-6
