@@ -231,3 +231,18 @@ def test_train_in_blocksolve_mode_follows_the_oracle_schedule(min_rate):
     assert stats.n_checks == 7
     for g, w in ((gP, P), (gQ, Q), (gub, ub), (gib, ib)):
         assert float(np.abs(g.astype(np.float64) - w).max()) <= 5e-6
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_blocksolve_random_shapes_long_chains(min_rate, case):
+    """Long chains (hundreds to thousands of links per item and iteration: the ring of LDS slots, the loaders' register pipeline,
+    the solvers' meeting points all cycle many times) at row widths from every compiled bucket, drawn from a fixed seed."""
+    rng = np.random.RandomState(1000 + case)
+    f = int(rng.choice([3, 8, 17, 33, 64, 100, 112, 128, 160, 200, 250]))
+    items = int(rng.choice([3, 5, 9, 20]))
+    users = int(rng.randint(4000, 16000))
+    per_user = int(rng.randint(2, min(items, 6) + 1))
+    min_rate(float(rng.choice([0.5, 50.0, 400.0])))
+    tr, _ = synth.make_ratings(users, items, users * per_user, min_degree=min(2, per_user), seed=case)
+    model, state = _run_both(tr, f, int(rng.randint(2, 5)))
+    assert max(_max_diffs(model, state)) <= 3e-6, (f, items, users)
