@@ -413,7 +413,7 @@ def main():
             "test_rmse": final["rmse"], "test_rmse_initial": rmse0, "iterations_run": final_iterations,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "traffic_from_profile": "profiles/ (rocprofv3 --pmc passes, fabric-side counters)",
-                         "kernel": kernels[mode], "bytes_per_update": bytes_per_update,
+                         "kernel": kernels.get(mode, mode), "bytes_per_update": bytes_per_update,
                          "algorithmic_bytes": alg_bytes, "device_seconds": elapsed_dev,
                          "note": "algorithmic bytes of the timed region (rank 0's updates x (16 f + 32)) / its duration by HIP events on "
                                  "the launch stream; the mode's sequential chains are latency bound, not bandwidth bound: DESIGN.md section 4"},
