@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--factors", type=int, default=100)
     ap.add_argument("--mode", default="blocksolve", choices=["blocksolve", "hogwild", "serial", "ordered"])
     ap.add_argument("--sync-every", type=int, default=0, help="steps between item-factor all-reduces (0 = one epoch)")
-    ap.add_argument("--merge", default="weighted", choices=["mean", "sum", "weighted"])
+    ap.add_argument("--merge", default="adaptive", choices=["mean", "sum", "weighted", "adaptive"])
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="strong (default): ONE dataset, users sharded across the ranks (BASELINE.json configs[3]); weak: "
                          "every rank holds its own full-size user population")

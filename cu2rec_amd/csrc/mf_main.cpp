@@ -196,7 +196,7 @@ int main(int argc, char **argv) {
     if (argc < 2) return -1;  // mf.cu:17-19
     std::string config_path;
     int mode = CU2REC_SGD_HOGWILD;
-    int gpus = 1, sync_every = 0, merge = CU2REC_MERGE_WEIGHTED;
+    int gpus = 1, sync_every = 0, merge = CU2REC_MERGE_ADAPTIVE;
     int opt;
     while ((opt = getopt(argc, argv, "c:m:g:s:w:")) != -1) {
         switch (opt) {
@@ -207,7 +207,10 @@ int main(int argc, char **argv) {
                 sync_every = std::atoi(optarg);
                 break;
             case 'w':
-                merge = std::strcmp(optarg, "mean") == 0 ? CU2REC_MERGE_MEAN : std::strcmp(optarg, "sum") == 0 ? CU2REC_MERGE_SUM : CU2REC_MERGE_WEIGHTED;
+                merge = std::strcmp(optarg, "mean") == 0       ? CU2REC_MERGE_MEAN
+                        : std::strcmp(optarg, "sum") == 0      ? CU2REC_MERGE_SUM
+                        : std::strcmp(optarg, "adaptive") == 0 ? CU2REC_MERGE_ADAPTIVE
+                                                               : CU2REC_MERGE_WEIGHTED;
                 break;
             case 'c':
                 config_path = optarg;
@@ -226,7 +229,7 @@ int main(int argc, char **argv) {
     }
     if (optind + 2 > argc) {
         std::cerr << "usage: mf [-c config] [-m hogwild|ordered|blocksolve|serial|pingpong] [-g gpus] [-s sync_every] "
-                     "[-w mean|weighted|sum] train.csv test.csv\n";
+                     "[-w mean|weighted|sum|adaptive] train.csv test.csv\n";
         return -1;
     }
     if (gpus > 1) {

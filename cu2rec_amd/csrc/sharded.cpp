@@ -146,7 +146,8 @@ ShardJob::ShardJob(Comm &comm_, DeviceModel &model_, const DeviceCsr &train_, in
                    const cu2rec_shard_options &opt)
     : comm(comm_), model(model_), train(train_), user_offset(user_offset_), sync_every(opt.sync_every), merge(opt.merge) {
     require(train.rows <= model.rows && train.max_item < model.cols, "cu2rec_shard_job: ratings exceed the model's shape");
-    require(merge == CU2REC_MERGE_MEAN || merge == CU2REC_MERGE_WEIGHTED || merge == CU2REC_MERGE_SUM, "cu2rec_shard_job: unknown merge");
+    require(merge == CU2REC_MERGE_MEAN || merge == CU2REC_MERGE_WEIGHTED || merge == CU2REC_MERGE_SUM || merge == CU2REC_MERGE_ADAPTIVE,
+            "cu2rec_shard_job: unknown merge");
     require(user_offset >= 0, "cu2rec_shard_job: negative user offset");
     require_device();
     const size_t nq = static_cast<size_t>(model.cols) * model.ldq;
@@ -165,7 +166,7 @@ ShardJob::ShardJob(Comm &comm_, DeviceModel &model_, const DeviceCsr &train_, in
     nnz_total = totals[1];
     if (sync_every <= 0)  // "each epoch" (north star): one epoch = nnz / users iterations, SURVEY.md section 8e
         sync_every = std::max(1, static_cast<int>(std::lround(nnz_total / std::max(users_total, 1.0))));
-    if (merge == CU2REC_MERGE_WEIGHTED && comm.nranks > 1) {
+    if ((merge == CU2REC_MERGE_WEIGHTED || merge == CU2REC_MERGE_ADAPTIVE) && comm.nranks > 1) {
         // w_k[y] = rate_k[y] / sum_j rate_j[y], rate = sum over the shard's raters of 1 / degree (host, double: the same
         // bits every run); items nobody rates anywhere keep weight 1 / N (their delta is zero anyway)
         std::vector<int> indptr(static_cast<size_t>(train.rows) + 1), indices(static_cast<size_t>(std::max(train.nnz, 1)));
@@ -183,14 +184,31 @@ ShardJob::ShardJob(Comm &comm_, DeviceModel &model_, const DeviceCsr &train_, in
         CU2REC_HIP(hipDeviceSynchronize());
         all.download(total.data(), total.size());
         std::vector<float> w(rate.size());
-        for (size_t y = 0; y < rate.size(); ++y) w[y] = static_cast<float>(total[y] > 0 ? rate[y] / total[y] : 1.0 / comm.nranks);
+        if (merge == CU2REC_MERGE_WEIGHTED) {
+            for (size_t y = 0; y < rate.size(); ++y) w[y] = static_cast<float>(total[y] > 0 ? rate[y] / total[y] : 1.0 / comm.nranks);
+        } else {
+            // Adaptive: the deltas are SUMMED and scaled per item by alpha = phi(r_total) / sum_k phi(r_k), phi(r) = 1 - exp(-c r):
+            // a shard's delta of an item row is, to first order, the progress phi of its own updates towards a common
+            // target, and all shards' updates in sequence would make phi of the total -- alpha is 1 for an item that is
+            // rarely updated (the sum is what the sequential run does) and 1 / N for an item every shard updates many times
+            // per iteration (the mean).  c = 6 fitted on the ML-20M shape (tools/shard_study.py, profiles/r02_shard_study_*).
+            double c = 6.0;
+            if (const char *env = std::getenv("CU2REC_MERGE_ADAPTIVE_C")) c = std::max(1e-3, std::atof(env));
+            std::vector<double> phi(rate.size());
+            for (size_t y = 0; y < rate.size(); ++y) phi[y] = -std::expm1(-c * rate[y]);
+            all.upload(phi.data(), phi.size());
+            comm.allreduce(all.ptr, phi.size(), true, nullptr);
+            CU2REC_HIP(hipDeviceSynchronize());
+            all.download(phi.data(), phi.size());  // now the sum over the ranks
+            for (size_t y = 0; y < rate.size(); ++y) w[y] = static_cast<float>(phi[y] > 0 ? -std::expm1(-c * total[y]) / phi[y] : 1.0);
+        }
         weight.allocate(w.size());
         weight.upload(w.data(), w.size());
     }
 }
 
 float ShardJob::scale() const {
-    return merge == CU2REC_MERGE_MEAN ? 1.f / static_cast<float>(comm.nranks) : 1.f;  // weighted: the weights sum to one
+    return merge == CU2REC_MERGE_MEAN ? 1.f / static_cast<float>(comm.nranks) : 1.f;  // weighted / adaptive: in the weights
 }
 
 void ShardJob::exchange(hipStream_t stream) {

@@ -21,7 +21,7 @@ def main(argv=None):
     ap.add_argument("-c", dest="config", default=None)
     ap.add_argument("-m", dest="mode", default="hogwild", choices=["hogwild", "ordered", "blocksolve", "serial"])
     ap.add_argument("--sync-every", type=int, default=0)
-    ap.add_argument("--merge", default="weighted", choices=["mean", "sum", "weighted"])
+    ap.add_argument("--merge", default="adaptive", choices=["mean", "sum", "weighted", "adaptive"])
     ap.add_argument("train")
     ap.add_argument("test")
     args = ap.parse_args(argv)

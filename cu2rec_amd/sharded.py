@@ -11,7 +11,7 @@ import numpy as np
 from . import api
 from ._lib import Config, Hyper, TrainStats, check, lib
 
-MERGES = {"mean": 0, "weighted": 1, "sum": 2}
+MERGES = {"mean": 0, "weighted": 1, "sum": 2, "adaptive": 3}
 
 
 class ShardOptions(C.Structure):

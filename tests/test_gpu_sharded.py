@@ -105,7 +105,7 @@ def _two_rank_worker(rank, world, port, out_dir, merge):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("merge", ["mean", "weighted"])
+@pytest.mark.parametrize("merge", ["mean", "weighted", "adaptive"])
 def test_two_ranks_one_gpu_cpp_driver_matches_oracle(tmp_path, merge):
     """cu2rec_train_sharded on two ranks (ordered mode: deterministic per shard), exchanges every 3 iterations, against the
     oracle running both shards and merging with numpy: P slices and user biases bit for bit, the item side within one
@@ -127,6 +127,13 @@ def test_two_ranks_one_gpu_cpp_driver_matches_oracle(tmp_path, merge):
         rates = [cu.api.item_update_rates(tr.slice_users(u0, u1)) for u0, u1 in bounds]
         tot = rates[0] + rates[1]
         w = [np.where(tot > 0, rk / np.where(tot > 0, tot, 1), 0.5).astype(np.float32) for rk in rates]
+        scale = np.float32(1.0)
+    elif merge == "adaptive":  # the sum, scaled per item by phi(r_total) / sum_k phi(r_k), phi(r) = 1 - exp(-6 r)
+        rates = [cu.api.item_update_rates(tr.slice_users(u0, u1)).astype(np.float64) for u0, u1 in bounds]
+        phi = lambda r: -np.expm1(-6.0 * r)
+        den = phi(rates[0]) + phi(rates[1])
+        alpha = np.where(den > 0, phi(rates[0] + rates[1]) / np.where(den > 0, den, 1), 1.0).astype(np.float32)
+        w = [alpha, alpha]
         scale = np.float32(1.0)
     else:
         w = [np.ones(tr.cols, np.float32)] * 2

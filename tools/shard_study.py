@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--sync", default="16,115")
     ap.add_argument("--mode", default="hogwild")
     ap.add_argument("--merges", default="mean,sum,weighted")
+    ap.add_argument("--gamma", default="", help="adaptive merge, exploratory form: contraction per update of an item row; comma list "
+                    "(phi(n) = 1 - (1 - gamma)^n with n = rate x sync).  Empty: the driver's form, phi(r) = 1 - exp(-6 r)")
     ap.add_argument("--sequential", action="store_true",
                     help="also run the unsharded set in ordered mode (= mf_sequential.cu's result, bit for bit) as the reference")
     args = ap.parse_args()
@@ -71,7 +73,20 @@ def main():
         tot = rates.sum(0)
         weights = torch.tensor(np.where(tot > 0, rates / np.maximum(tot, 1e-300), 1.0 / n), dtype=torch.float32, device=dev)
         for sync in [int(v) for v in args.sync.split(",")]:
+            merges = []
             for merge in args.merges.split(","):
+                merges += [(merge, None)] if merge != "adaptive" else ([("adaptive", float(g)) for g in args.gamma.split(",")] if args.gamma
+                                                                       else [("adaptive", 0.0)])
+            for merge, gamma in merges:
+                if merge == "adaptive":
+                    # every shard's delta of an item row is (to first order) the progress phi(n_k) = 1 - (1 - gamma)^n_k of its
+                    # n_k updates towards a common target; all N shards' updates in sequence make phi(sum n_k): the SUM of the
+                    # deltas is scaled by phi(n_tot) / sum_k phi(n_k) -- 1 for rarely updated items (a plain sum), 1 / N for
+                    # items every shard saturates within a period (the mean)
+                    n_k = rates * sync if gamma > 0 else rates
+                    phi = (lambda x: -np.expm1(x * np.log1p(-gamma))) if gamma > 0 else (lambda x: -np.expm1(-6.0 * x))
+                    alpha = np.where(tot > 0, phi(n_k.sum(0)) / np.maximum(phi(n_k).sum(0), 1e-300), 1.0)
+                    alpha_t = torch.tensor(alpha, dtype=torch.float32, device=dev)
                 engines = [Engine(u1 - u0, train.cols, f, train.global_bias, P=P0[u0:u1], user_bias=ub0[u0:u1], device=dev)
                            for u0, u1 in bounds]
                 d = [DeviceRatings(s, dev) for s in shards]
@@ -88,6 +103,9 @@ def main():
                         Qb, ibb = Qb + dQ.mean(0), ibb + dib.mean(0)
                     elif merge == "sum":
                         Qb, ibb = Qb + dQ.sum(0), ibb + dib.sum(0)
+                    elif merge == "adaptive":
+                        Qb = Qb + alpha_t[:, None] * dQ[:, :train.cols].sum(0)
+                        ibb = ibb + alpha_t * dib[:, :train.cols].sum(0)
                     else:
                         Qb = Qb + (weights[:, :, None] * dQ[:, :train.cols]).sum(0)
                         ibb = ibb + (weights * dib[:, :train.cols]).sum(0)
@@ -95,8 +113,9 @@ def main():
                         e.Q.copy_(Qb)
                         e.item_bias.copy_(ibb)
                 r = test_rmse(engines, bounds)
-                results.append({"shards": n, "sync_every": sync, "merge": merge, "rmse": r, "delta_vs_n1": r - ref})
-                print("N=%d sync=%d merge=%-8s rmse %.5f (%+.5f vs N=1)" % (n, sync, merge, r, r - ref), flush=True)
+                name = merge if not gamma else "%s(gamma=%g)" % (merge, gamma)
+                results.append({"shards": n, "sync_every": sync, "merge": name, "rmse": r, "delta_vs_n1": r - ref})
+                print("N=%d sync=%d merge=%-8s rmse %.5f (%+.5f vs N=1)" % (n, sync, name, r, r - ref), flush=True)
                 del engines, d
     print(json.dumps({"workload": args.workload, "f": f, "iters": args.iters, "mode": args.mode, "results": results}))
 
