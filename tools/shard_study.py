@@ -92,6 +92,33 @@ def main():
                 d = [DeviceRatings(s, dev) for s in shards]
                 Qb, ibb = engines[0].Q.clone(), engines[0].item_bias.clone()
                 it = 0
+                if merge.startswith("twotier"):
+                    # exploratory: the items every shard updates all the time (total rate >= 1) are reconciled every `fast`
+                    # iterations (their deltas scaled as in the adaptive merge), everything every `sync` iterations
+                    fast = int(merge[len("twotier"):] or 8)
+                    hot = torch.tensor(tot >= 1.0, device=dev)
+                    phi = lambda x: -np.expm1(-6.0 * x)
+                    alpha_t = torch.tensor(np.where(tot > 0, phi(tot) / np.maximum(phi(rates).sum(0), 1e-300), 1.0), dtype=torch.float32, device=dev)
+                    nh = int(hot.sum().item())
+                    while it < args.iters:
+                        k = min(fast, args.iters - it, sync - (it % sync))
+                        for e, dr, (u0, _) in zip(engines, d, bounds):
+                            e.sgd(dr, hyper, 42, it, k, args.mode, True, u0)
+                        it += k
+                        full = it % sync == 0 or it == args.iters
+                        sel = torch.ones_like(hot) if full else hot
+                        dQ = torch.stack([e.Q[:train.cols] - Qb[:train.cols] for e in engines]).sum(0)
+                        dib = torch.stack([e.item_bias[:train.cols] - ibb[:train.cols] for e in engines]).sum(0)
+                        Qb[:train.cols][sel] += (alpha_t[:, None] * dQ)[sel]
+                        ibb[:train.cols][sel] += (alpha_t * dib)[sel]
+                        for e in engines:
+                            e.Q[:train.cols][sel] = Qb[:train.cols][sel]
+                            e.item_bias[:train.cols][sel] = ibb[:train.cols][sel]
+                    r = test_rmse(engines, bounds)
+                    results.append({"shards": n, "sync_every": sync, "merge": merge, "hot_items": nh, "rmse": r, "delta_vs_n1": r - ref})
+                    print("N=%d sync=%d merge=%-8s (%d hot items) rmse %.5f (%+.5f vs N=1)" % (n, sync, merge, nh, r, r - ref), flush=True)
+                    del engines, d
+                    continue
                 while it < args.iters:
                     k = min(sync, args.iters - it)
                     for e, dr, (u0, _) in zip(engines, d, bounds):
