@@ -217,6 +217,13 @@ class DeviceCSR:
         check(lib().cu2rec_csr_device_ptrs(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def blocksolve_items(self):
+        """cu2rec_csr_blocksolve_items: how many items the block-solve mode solves block-wise here (0: it is the ordered walk)."""
+        n = lib().cu2rec_csr_blocksolve_items(self._h)
+        if n < 0:
+            check(-1)
+        return n
+
     def close(self):
         if self._h:
             lib().cu2rec_csr_destroy(self._h)
@@ -297,9 +304,15 @@ class Model:
             pass
 
 
-def train(train_matrix, test_matrix, cfg, Q=None, item_bias=None, global_bias=None, mode=SGD_HOGWILD, verbose=True,
+def default_mode(n_factors):
+    """The default SGD mode of train(), bin/mf and bench.py: block-solve (mf_sequential.cu's result within float rounding, the mode
+    certified against the 1e-4 RMSE bar); above 252 factors, where it is not compiled, `ordered` (the same result bit for bit)."""
+    return SGD_BLOCKSOLVE if n_factors <= 252 else SGD_ORDERED
+
+
+def train(train_matrix, test_matrix, cfg, Q=None, item_bias=None, global_bias=None, mode=None, verbose=True,
           P=None, user_bias=None, return_stats=False):
-    """train() (training.h:12-15).  train_matrix / test_matrix: DeviceCSR (or HostCSR, uploaded here).
+    """train() (training.h:12-15).  mode None = default_mode(cfg.n_factors); "hogwild" opts into sgd.cu's racy semantics.  train_matrix / test_matrix: DeviceCSR (or HostCSR, uploaded here).
     Q / item_bias given = the 11-argument overload (caller-initialised item side, predict.cu:126);
     otherwise everything starts from the seed-42 normal init.  Returns (P, Q, losses, user_bias,
     item_bias) like the reference's out-pointers; cfg.learning_rate / cfg.cur_iterations are
@@ -310,6 +323,7 @@ def train(train_matrix, test_matrix, cfg, Q=None, item_bias=None, global_bias=No
     model = Model(tr.rows, tr.cols, cfg.n_factors, gb, P=P, Q=Q, user_bias=user_bias, item_bias=item_bias)
     losses = np.empty(max(cfg.total_iterations, 1), np.float32)
     stats = TrainStats()
+    mode = default_mode(cfg.n_factors) if mode is None else mode
     check(lib().cu2rec_train(tr._h, te._h, C.byref(cfg), model._h, _mode(mode), 1 if verbose else 0, _ptr(losses),
                              C.byref(stats)))
     Pn, Qn, ub, ib = model.download()
@@ -375,7 +389,9 @@ def sgd_update_blocksolve(schedule, indptr, indices, data, n_rows, n_cols, P, ld
 
 
 def blocksolve_min_rate(rate=0.0):
-    """cu2rec_blocksolve_min_rate: expected updates per iteration from which an item's chain is solved block-wise."""
+    """cu2rec_blocksolve_min_rate: expected updates per iteration from which an item's chain is solved block-wise.
+    rate > 0 sets it, rate < 0 returns to the automatic threshold, 0 queries; returns what was in force before (-1: automatic),
+    so blocksolve_min_rate(previous) restores either state."""
     return lib().cu2rec_blocksolve_min_rate(float(rate))
 
 

@@ -1099,12 +1099,7 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
 template <int SW>
 void launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     const size_t lds = std::max(solve_lds_bytes(a.nslots, SW), it.aff_min_blocks > 0 ? affine_lds_bytes(a.nslots) : static_cast<size_t>(0));
-    static bool attr_set = false;  // one per instantiation
-    if (!attr_set) {
-        CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bs_solve_kernel<SW>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW>));
     const int helpers = it.pf_helpers > 0 ? 8 * it.pf_helpers * it.pf_chains : 0;
     const int grid = helpers > 0 ? ((it.n_hot + 7) & ~7) + helpers : it.n_hot;
     hipLaunchKernelGGL(bs_solve_kernel<SW>, dim3(grid), dim3(512), lds, stream, a, it);
@@ -1148,12 +1143,7 @@ void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream)
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
     const size_t gram_lds = static_cast<size_t>(kB) * (a.nslots | 1) * 16 +
                             (static_cast<size_t>(5) * kH * kMS + (it.aff_min_blocks > 0 ? kGramExtFloats : 0) + kGramTabFloats + kB) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bs_gram_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_gram_kernel));
     hipLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), gram_lds, stream, a, it);
     CU2REC_HIP(hipGetLastError());
 }
@@ -1174,12 +1164,7 @@ void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream
 void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
     const int ntiles = (4 * a.nslots + 31) / 32;
-    static bool attr_set = false;
-    if (!attr_set) {
-        CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bs_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024));
-        attr_set = true;
-    }
+    ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_update_kernel));
     hipLaunchKernelGGL(bs_update_kernel, dim3(it.max_blocks), dim3(64 * ntiles), update_lds_bytes(ntiles), stream, a, it, ntiles);
     CU2REC_HIP(hipGetLastError());
 }

@@ -357,7 +357,7 @@ void DeviceModel::sgd(const DeviceCsr &train, const cu2rec_hyper &h, uint64_t se
     }
     other_in_sync = false;  // another mode moves Q on without the second pair
     if (mode == CU2REC_SGD_ORDERED || mode == CU2REC_SGD_BLOCKSOLVE) {
-        if (!train.schedule) {
+        if (!train.schedule || train.schedule->n_cols != cols) {
             train.schedule.reset(new OrderedSchedule(train.indptr.ptr, train.indices.ptr, train.rows, cols, train.nnz));
             train.schedule->speculate = true;  // the schedule is destroyed with the arrays it reads
         }
@@ -548,6 +548,20 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
 }
 
 float cu2rec_blocksolve_min_rate(float rate) { return blocksolve_min_rate(rate); }
+
+int cu2rec_csr_blocksolve_items(const cu2rec_csr *train) {
+    int n = -1;
+    const int rc = guarded([&] {
+        require(train, "cu2rec_csr_blocksolve_items: null argument");
+        const DeviceCsr &m = unwrap(train);
+        if (!m.schedule) {
+            m.schedule.reset(new OrderedSchedule(m.indptr.ptr, m.indices.ptr, m.rows, m.cols, m.nnz));
+            m.schedule->speculate = true;
+        }
+        n = m.schedule->n_hot_bs;
+    });
+    return rc == CU2REC_OK ? n : -1;
+}
 
 int cu2rec_blocksolve_affine_blocks(int blocks) { return blocksolve_affine_blocks(blocks); }
 

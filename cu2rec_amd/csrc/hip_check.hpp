@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <set>
 #include <sstream>
 #include <utility>
 
@@ -28,6 +30,19 @@ inline void require_device() {
         (void)hipGetLastError();
         fail(CU2REC_ENODEVICE, "cu2rec_amd: no HIP device available; the SGD/loss path is GPU-only (no CPU fallback)");
     }
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device): set once for each pair, whichever device
+// is current when a launch needs it (a process-wide "done" flag would leave the second device of a process at 64 KB).
+inline void ensure_max_dynamic_lds(const void *kernel, int bytes = 160 * 1024) {
+    static std::mutex mutex;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    CU2REC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mutex);
+    if (done.count({dev, kernel})) return;
+    CU2REC_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({dev, kernel});
 }
 
 template <class T>

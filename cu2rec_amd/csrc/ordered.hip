@@ -607,7 +607,7 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     // the launch overhead it has to beat does not shrink with it; 1/1 .. 1/8 of the ML-20M shape,
     // profiles/r02_shard_size_probe_blocksolve.log) and up (Netflix shape, 480,189 users: 290 us per iteration at 800
     // against 353 at 240 -- the chains of several hundred hot items do not fit the CUs at once)
-    float min_rate = blocksolve_min_rate(-1.f);
+    float min_rate = blocksolve_min_rate_base();
     if (!blocksolve_min_rate_is_set()) {
         min_rate = std::max(30.f, min_rate * static_cast<float>(n_active) / 131072.f);
         // no chain long enough to pay for three launches and two events per iteration: the ordered walk alone is faster
@@ -655,31 +655,37 @@ OrderedSchedule::~OrderedSchedule() {
 }
 
 namespace {
-std::atomic<float> g_bs_min_rate{-1.f};
-std::atomic<bool> g_bs_min_rate_set{false};
+// explicit threshold (> 0), or <= 0: automatic (240 per 131,072 rating users, scaled with the set); -2 = not yet initialised
+// from the environment
+std::atomic<float> g_bs_min_rate{-2.f};
+constexpr float kBsDefaultRate = 240.f;
+
+float bs_min_rate_state() {
+    float cur = g_bs_min_rate.load();
+    if (cur == -2.f) {  // first use: CU2REC_BLOCKSOLVE_RATE overrides the automatic threshold
+        float init = -1.f;
+        if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_RATE")) init = std::max(0.01f, static_cast<float>(std::atof(env)));
+        g_bs_min_rate.compare_exchange_strong(cur, init);
+        cur = g_bs_min_rate.load();
+    }
+    return cur;
+}
+}  // namespace
+
+bool blocksolve_min_rate_is_set() { return bs_min_rate_state() > 0.f; }
+
+float blocksolve_min_rate_base() {
+    const float cur = bs_min_rate_state();
+    return cur > 0.f ? cur : kBsDefaultRate;
 }
 
-bool blocksolve_min_rate_is_set() {
-    (void)blocksolve_min_rate(-1.f);
-    return g_bs_min_rate_set.load();
-}
-
+// rate > 0: explicit threshold; rate < 0: back to automatic; rate == 0: query.  Returns what was in force before the call:
+// the explicit value, or -1 for automatic -- so that f(f(x)) restores either state.
 float blocksolve_min_rate(float rate) {
-    float prev = g_bs_min_rate.load();
-    if (prev < 0.f) {  // first use: default 240 expected updates per iteration, CU2REC_BLOCKSOLVE_RATE overrides
-        float init = 240.f;
-        if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_RATE")) {
-            init = std::max(0.01f, static_cast<float>(std::atof(env)));
-            g_bs_min_rate_set.store(true);
-        }
-        g_bs_min_rate.compare_exchange_strong(prev, init);
-        prev = g_bs_min_rate.load();
-    }
-    if (rate > 0.f) {
-        g_bs_min_rate.store(rate);
-        g_bs_min_rate_set.store(true);
-    }
-    return prev;
+    const float prev = bs_min_rate_state();
+    if (rate > 0.f) g_bs_min_rate.store(rate);
+    else if (rate < 0.f) g_bs_min_rate.store(-1.f);
+    return prev > 0.f ? prev : -1.f;
 }
 
 namespace {

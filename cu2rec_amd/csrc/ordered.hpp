@@ -52,7 +52,7 @@ struct OrderedSchedule {
     // ranks [0, n_hot_bs) -- at least blocksolve_min_rate() expected updates -- get the block-wise treatment
     int n_hot_bs = 0;
     int n_duo_bs = 0;        // ranks [n_hot_bs, n_duo_bs): the ordered mode's two-wave chains, beside the block solves
-    int max_blocks = 0;      // blocks of 32 links per iteration, upper bound
+    int max_blocks = 0;      // blocks of 64 links (kBsLinks) per iteration, upper bound
     int qstart_ld = 0;
     SgdHyper tables_for{};   // hyper-parameters the decay tables were computed from
     bool tables_valid = false;
@@ -71,7 +71,10 @@ struct OrderedSchedule {
 };
 
 // minimum expected updates per iteration of an item for block-wise treatment (process-wide; schedules created later)
+// rate > 0 sets it, rate < 0 returns to automatic (scaled with the set), 0 queries; returns the explicit value in force before
+// the call or -1 for automatic
 float blocksolve_min_rate(float rate);
+float blocksolve_min_rate_base();   // the explicit value, or the default the automatic scaling starts from
 bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwise a schedule scales the default with its set
 // chains of at least this many blocks of 64 links take the affine form (0: none); blocks < 0 only queries
 int blocksolve_affine_blocks(int blocks);

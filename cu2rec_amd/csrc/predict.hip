@@ -135,11 +135,7 @@ __global__ __launch_bounds__(256) void take_top_kernel(const float *__restrict__
 void launch_scores(const DeviceModel &m, int user0, int n_users, float *scores, hipStream_t stream) {
     const int nslots = (m.n_factors + 3) / 4;
     const size_t lds = static_cast<size_t>(5) * kTile * (nslots | 1) * 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        CU2REC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scores_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    ensure_max_dynamic_lds(reinterpret_cast<const void *>(scores_kernel));
     const dim3 grid((m.cols + 4 * kTile - 1) / (4 * kTile), (n_users + kTile - 1) / kTile);
     hipLaunchKernelGGL(scores_kernel, grid, dim3(256), lds, stream, m.P.ptr + static_cast<size_t>(user0) * m.ld, m.ld,
                        m.user_bias.ptr + user0, n_users, m.Q.ptr, m.ldq, m.item_bias.ptr, m.cols, m.global_bias, nslots, scores);

@@ -679,12 +679,13 @@ bool resident_launch(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream)
     const hipError_t launched = s.cooperative
                                     ? hipLaunchCooperativeKernel(kVariants[variant].kernel, dim3(blocks), dim3(kResBlock), args, 0, stream)
                                     : hipLaunchKernel(kVariants[variant].kernel, dim3(blocks), dim3(kResBlock), args, 0, stream);
-    if (launched != hipSuccess) {
-        (void)hipGetLastError();
+    if (launched == hipErrorCooperativeLaunchTooLarge || launched == hipErrorLaunchOutOfResources) {
+        (void)hipGetLastError();  // a refusal: the grid cannot be co-resident on this device -- stream instead, and do not ask again
         s.usable[variant] = false;
         ++s.refused;
         return false;
     }
+    CU2REC_HIP(launched);  // anything else (lost device, a sticky error of an earlier kernel, bad configuration) is an error
     CU2REC_HIP(hipMemcpyAsync(s.host_status, s.words + kBarrierWords, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     CU2REC_HIP(hipEventRecord(s.done, stream));
     s.last_stream = stream;

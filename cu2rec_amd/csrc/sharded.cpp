@@ -332,7 +332,7 @@ int cu2rec_shard_job_create(cu2rec_comm *comm, cu2rec_model *model, const cu2rec
     return guarded([&] {
         require(comm && comm->impl && model && train && out, "cu2rec_shard_job_create: null argument");
         *out = nullptr;
-        cu2rec_shard_options opt{0, CU2REC_MERGE_MEAN};
+        cu2rec_shard_options opt{0, CU2REC_MERGE_ADAPTIVE};  // the one default everywhere (bin/mf, bench.py, the Python mirror)
         if (options) opt = *options;
         *out = new cu2rec_shard_job(*comm->impl, unwrap(model), unwrap(train), user_offset, opt);
     });

@@ -1,7 +1,8 @@
 """bin/mf across the GPUs of one node: one process per GPU over RCCL.
 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      -m cu2rec_amd.mf_mgpu -c ml.cfg [-m hogwild|ordered] [--sync-every K] [--merge mean|sum] train.csv test.csv
+      -m cu2rec_amd.mf_mgpu -c ml.cfg [-m blocksolve|ordered|hogwild|serial] [--sync-every K]
+      [--merge adaptive|mean|weighted|sum] train.csv test.csv   (defaults: blocksolve, adaptive -- as bin/mf)
 
 Same stdout lines and the same five output CSVs as bin/mf (mf.cu:16-99); rank 0 prints and writes.
 A thin launcher: ratings are sharded by user and trained by the C++ driver (cu2rec_amd/csrc/sharded.cpp,
@@ -19,7 +20,7 @@ import numpy as np
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="cu2rec_amd.mf_mgpu")
     ap.add_argument("-c", dest="config", default=None)
-    ap.add_argument("-m", dest="mode", default="hogwild", choices=["hogwild", "ordered", "blocksolve", "serial"])
+    ap.add_argument("-m", dest="mode", default=None, choices=["hogwild", "ordered", "blocksolve", "serial"])
     ap.add_argument("--sync-every", type=int, default=0)
     ap.add_argument("--merge", default="adaptive", choices=["mean", "sum", "weighted", "adaptive"])
     ap.add_argument("train")
@@ -48,7 +49,7 @@ def main(argv=None):
     if rank == 0:
         cu.print_config(cfg)
     comm = Comm(rank, world, share=share_through_torch(device) if world > 1 else None)
-    P, Q, losses, ub, ib, (u0, u1), _ = train_sharded(comm, train, test, cfg, mode=args.mode, sync_every=args.sync_every,
+    P, Q, losses, ub, ib, (u0, u1), _ = train_sharded(comm, train, test, cfg, mode=args.mode or cu.api.default_mode(cfg.n_factors), sync_every=args.sync_every,
                                                       merge=args.merge, verbose=True)
     # gather the user side on rank 0 (rows are contiguous per rank)
     if world > 1:

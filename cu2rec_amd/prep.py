@@ -1,7 +1,9 @@
 """Data preparation equivalents of the reference's preprocessing scripts, so raw
 `userId,itemId,rating[,...]` files can be taken to the trainer's input format without the reference tree.
-Only the FILE FORMATS matter (ids 1..N in first-seen order, rows sorted by user, one header line,
-9-field config); bit parity with Python's `random` shuffle in the reference's splitter is not a goal.
+The outputs equal the reference scripts' byte for byte on the same input (tests/test_prep.py against files produced by the
+reference's own scripts, oracle/gen_prep_golden.py): ids 1..N in first-seen order, rows stably sorted by user, one header line,
+ratings printed as Python prints a float ("4.0", "2.5"), the split = `random.seed(seed)`, one shuffle of all rows, the first
+int(n * (1 - test_ratio)) of them for training, both halves stably sorted by user; 9-field config without a newline.
 
   python -m cu2rec_amd.prep map    ratings.csv            -> ratings_mapped.csv   (preprocessing/map_items.py:21-89)
   python -m cu2rec_amd.prep split  ratings_mapped.csv     -> *_train.csv, *_test.csv (split_to_test_train.py:39-78)
@@ -9,6 +11,7 @@ Only the FILE FORMATS matter (ids 1..N in first-seen order, rows sorted by user,
 """
 import argparse
 import os
+import random
 import sys
 
 import numpy as np
@@ -26,7 +29,7 @@ def _read_triples(path):
             users.append(int(parts[0]))
             items.append(int(parts[1]))
             ratings.append(float(parts[2]))
-    return np.asarray(users, np.int64), np.asarray(items, np.int64), np.asarray(ratings, np.float32)
+    return np.asarray(users, np.int64), np.asarray(items, np.int64), np.asarray(ratings, np.float64)
 
 
 def _first_seen_ids(values):
@@ -39,9 +42,10 @@ def _first_seen_ids(values):
 
 
 def _write(path, user, item, rating):
-    with open(path, "w") as fh:
+    """map_items.py:80-89: header, then `user,item,rating` with the rating as str(float) ("4.0", "2.5")."""
+    with open(path, "w", newline="") as fh:
         fh.write("userId,itemId,rating\n")
-        np.savetxt(fh, np.column_stack([user, item, rating]), fmt=["%d", "%d", "%g"], delimiter=",")
+        fh.write("".join("%d,%d,%s\n" % (u, i, repr(float(r))) for u, i, r in zip(user.tolist(), item.tolist(), rating.tolist())))
 
 
 def map_ids(src, dst=None):
@@ -54,29 +58,38 @@ def map_ids(src, dst=None):
     return dst, int(user.max(initial=0)), int(item.max(initial=0)), len(user)
 
 
-def split(src, test_fraction=0.2, seed=42, train_dst=None, test_dst=None):
-    """Random per-rating split, both halves sorted by user (split_to_test_train.py:39-49,76-78).  Every user keeps
-    at least one training rating, so the test file never names a user the model does not have."""
+def split(src, test_fraction=0.2, seed=42, train_dst=None, test_dst=None, keep_users=False):
+    """split_to_test_train.py:39-49,69-78 (split_true): random.seed(seed), ONE shuffle of all rows, the first
+    int(n * (1 - test_fraction)) rows train, the rest test, both stably sorted by user -- the same files as the reference's
+    script.  keep_users=True (not the reference's behaviour) moves one rating of every user that ended up without a training
+    rating back from test to train, so that the test file never names a user the model has no ratings for."""
     user, item, rating = _read_triples(src)
-    rng = np.random.RandomState(seed)
-    is_test = rng.rand(len(user)) < test_fraction
-    first = np.zeros(len(user), bool)
-    first[np.unique(user, return_index=True)[1]] = True
-    is_test &= ~first
+    n = len(user)
+    order = list(range(n))
+    random.Random(seed).shuffle(order)  # the algorithm behind the reference's module-level random.seed / random.shuffle
+    order = np.asarray(order, np.int64)
+    n_train = int(n * (1 - test_fraction))
+    train_idx, test_idx = order[:n_train], order[n_train:]
+    if keep_users and n:
+        missing = np.setdiff1d(user[test_idx], user[train_idx])
+        if len(missing):
+            pos = np.asarray([np.flatnonzero(user[test_idx] == u)[0] for u in missing], np.int64)
+            train_idx = np.concatenate([train_idx, test_idx[pos]])
+            test_idx = np.delete(test_idx, pos)
     base = os.path.splitext(src)[0]
     train_dst, test_dst = train_dst or base + "_train.csv", test_dst or base + "_test.csv"
-    for dst, mask in ((train_dst, ~is_test), (test_dst, is_test)):
-        order = np.argsort(user[mask], kind="stable")
-        _write(dst, user[mask][order], item[mask][order], rating[mask][order])
+    for dst, idx in ((train_dst, train_idx), (test_dst, test_idx)):
+        idx = idx[np.argsort(user[idx], kind="stable")]
+        _write(dst, user[idx], item[idx], rating[idx])
     return train_dst, test_dst
 
 
 def write_config(path, total_iterations=5000, n_factors=50, learning_rate=0.01, seed=42, P_reg=0.02, Q_reg=0.02,
                  user_bias_reg=0.02, item_bias_reg=0.02):
-    """create_config.py:10-19: `0 %d %d %f %d %f %f %f %f`."""
+    """create_config.py:10-19: `0 %d %d %f %d %f %f %f %f`, no newline."""
     with open(path, "w") as fh:
-        fh.write("0 %d %d %f %d %f %f %f %f\n" % (total_iterations, n_factors, learning_rate, seed, P_reg, Q_reg,
-                                                 user_bias_reg, item_bias_reg))
+        fh.write("0 %d %d %f %d %f %f %f %f" % (total_iterations, n_factors, learning_rate, seed, P_reg, Q_reg,
+                                               user_bias_reg, item_bias_reg))
     return path
 
 
@@ -90,6 +103,7 @@ def main(argv=None):
     s.add_argument("src")
     s.add_argument("--test-fraction", type=float, default=0.2)
     s.add_argument("--seed", type=int, default=42)
+    s.add_argument("--keep-users", action="store_true", help="every user keeps at least one training rating (not the reference's behaviour)")
     c = sub.add_parser("config")
     c.add_argument("dst")
     c.add_argument("--iters", type=int, default=5000)
@@ -101,7 +115,7 @@ def main(argv=None):
     if args.cmd == "map":
         print("%s: %d users, %d items, %d ratings" % map_ids(args.src, args.dst))
     elif args.cmd == "split":
-        print("%s %s" % split(args.src, args.test_fraction, args.seed))
+        print("%s %s" % split(args.src, args.test_fraction, args.seed, keep_users=args.keep_users))
     else:
         print(write_config(args.dst, args.iters, args.factors, args.lr, args.seed, args.reg, args.reg, args.reg, args.reg))
     return 0

@@ -74,7 +74,7 @@ def share_through_torch(device=None):
 class ShardJob:
     """cu2rec_shard_job: one rank's share of a sharded run (model + train must outlive it)."""
 
-    def __init__(self, comm, model, train, user_offset=0, sync_every=0, merge="mean"):
+    def __init__(self, comm, model, train, user_offset=0, sync_every=0, merge="adaptive"):
         self.comm, self.model, self.ratings = comm, model, train
         opt = ShardOptions(int(sync_every), MERGES[merge] if isinstance(merge, str) else int(merge))
         self._h = C.c_void_p()
@@ -133,7 +133,7 @@ def shard_of(train, test, rank, nranks):
     return u0, u1, train.slice_users(u0, u1), test.slice_users(u0, u1)
 
 
-def train_sharded(comm, train, test, cfg, mode=api.SGD_HOGWILD, sync_every=0, merge="mean", verbose=True):
+def train_sharded(comm, train, test, cfg, mode=api.SGD_BLOCKSOLVE, sync_every=0, merge="adaptive", verbose=True):
     """train() (training.h:12-15) over all ranks through the C++ driver.  train / test: the FULL HostCSR on every rank.
     Returns (P_local, Q, losses, user_bias_local, item_bias, (u0, u1), stats)."""
     u0, u1, tr, te = shard_of(train, test, comm.rank, comm.nranks)

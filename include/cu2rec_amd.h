@@ -165,9 +165,11 @@ typedef enum cu2rec_sgd_mode {
      * cu2rec_train, bin/mf -m pingpong) or cu2rec_sgd_update_pingpong below. */
     CU2REC_SGD_PINGPONG = 3,
     /* mf_sequential.cu:102-143's semantics at Hogwild-class speed: the schedule of CU2REC_SGD_ORDERED, but the chain of
-     * a popular item (thousands of dependent updates per iteration) is solved 32 updates at a time -- their errors are
-     * the solution of a unit lower triangular system built from the Gram matrix of the 32 user rows (matrix cores), a
-     * scalar forward substitution replaces 32 dependent row updates (cu2rec_amd/csrc/blocksolve.hip).  Equal to the
+     * a popular item (thousands of dependent updates per iteration) is solved in blocks of 64 updates -- a block's errors
+     * are the solution of a unit lower triangular 64 x 64 system built from the Gram matrix of its 64 user rows (fp32
+     * matrix cores); its inverse, formed tile-wise ahead of the chain (two 32 x 32 triangular inversions + two matrix
+     * products), turns 64 dependent row updates into three mat-vecs per block (cu2rec_amd/csrc/blocksolve.hip).  This is
+     * the default of bin/mf and of bench.py, the mode certified against the north star's 1e-4 RMSE bar.  Equal to the
      * sequential result up to float rounding (sums are associated differently), NOT bit for bit: tests pin it at
      * |test RMSE - oracle| <= 1e-4 after 1,000 iterations of the ML-20M shape.  n_factors <= 252.  Needs a
      * cu2rec_schedule like CU2REC_SGD_ORDERED. */
@@ -276,7 +278,8 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
  * update.  Process-wide, read when a schedule is created; default 240 per 131,072 rating users, scaled with the set (no
  * less than 30: one GPU's shard of a strong-scaling run has shorter chains and the same launch overheads; the Netflix
  * shape's 480,189 users give 880); a value set here or by CU2REC_BLOCKSOLVE_RATE in the environment is taken as it is.
- * Returns the previous value; rate <= 0 only queries. */
+ * rate > 0 sets an explicit threshold, rate < 0 returns to the automatic one, rate == 0 only queries.  Returns what was in
+ * force before the call: the explicit threshold, or -1 for automatic (so passing a returned value back restores it). */
 float cu2rec_blocksolve_min_rate(float rate);
 /* Chains of at least `blocks` blocks of 64 updates (one item, one iteration) are advanced in the affine form: phase 1
  * also builds, per block, the matrix that maps the item's row and bias at the start of the block to those at its end,
@@ -319,6 +322,9 @@ int cu2rec_csr_create(int rows, int cols, int nnz, const int *indptr, const int 
 int cu2rec_csr_info(const cu2rec_csr *m, int *rows, int *cols, int *nnz);
 int cu2rec_csr_device_ptrs(const cu2rec_csr *m, const int **indptr, const int **indices, const float **data);
 void cu2rec_csr_destroy(cu2rec_csr *m);
+/* How many items CU2REC_SGD_BLOCKSOLVE solves block-wise on this rating matrix (creates its schedule on first use); 0 = the
+ * mode is the ordered walk there.  < 0 on error. */
+int cu2rec_csr_blocksolve_items(const cu2rec_csr *train);
 
 /* Host arrays are dense (row stride n_factors), the reference's layout; any of P/Q/biases may
  * be NULL = initialise like the reference: initialize_normal_array(..., seed 42)
@@ -447,7 +453,8 @@ typedef struct cu2rec_shard_options {
 } cu2rec_shard_options;
 
 typedef struct cu2rec_shard_job cu2rec_shard_job;
-/* model and train must outlive the job; options may be NULL (epoch cadence, mean). Collective: all ranks call it. */
+/* model and train must outlive the job; options may be NULL (epoch cadence, CU2REC_MERGE_ADAPTIVE: the default of bin/mf
+ * and bench.py). Collective: all ranks call it. */
 int cu2rec_shard_job_create(cu2rec_comm *comm, cu2rec_model *model, const cu2rec_csr *train, int user_offset,
                             const cu2rec_shard_options *options, cu2rec_shard_job **out);
 void cu2rec_shard_job_destroy(cu2rec_shard_job *job);

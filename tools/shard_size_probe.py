@@ -27,7 +27,7 @@ def main():
     import bench
     import cu2rec_amd as cu
     from cu2rec_amd.engine import DeviceRatings, Engine
-    from cu2rec_amd.parallel import plan_users
+    from cu2rec_amd.sharded import plan_users
     train, _ = bench.load_dataset(args.workload, 20240917, 0, lambda: None)
     dev = torch.device("cuda", 0)
     hyper = (0.01, 0.02, 0.02, 0.02, 0.02)

@@ -36,7 +36,7 @@ def main():
     import bench
     import cu2rec_amd as cu
     from cu2rec_amd.engine import DeviceRatings, Engine
-    from cu2rec_amd.parallel import plan_users
+    from cu2rec_amd.sharded import plan_users
 
     train, test = bench.load_dataset(args.workload, 20240917, 0, lambda: None)
     f, hyper = args.factors, (0.01, 0.02, 0.02, 0.02, 0.02)
