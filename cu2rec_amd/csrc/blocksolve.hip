@@ -27,8 +27,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <utility>
+#include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "blocksolve.hpp"
 #include "hip_check.hpp"
@@ -56,6 +58,39 @@ __device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 dup2(float v) { return f32x2{v, v}; }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// A 16-byte store that goes through the XCD's L2 to the memory side at once (sc1) instead of staying dirty in it: data another
+// workgroup of the SAME launch is waiting for.  The instruction is invisible to the compiler's s_waitcnt bookkeeping: every
+// publisher waits with an explicit s_waitcnt vmcnt before it announces anything.  (s_nop: the data registers of a wide store
+// must not be overwritten by the very next vector instruction; the compiler's hazard pass cannot look into the asm block.)
+__device__ __forceinline__ void store_through(float *p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v));  // (no memory clobber: it would fence the LDS traffic around it)
+}
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) {  // global_load sc1: never served from this CU's L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The same accesses as inline assembly, for the chain's loop (bs_solve_kernel): a vector-memory instruction the COMPILER knows of
+// inside that loop makes its s_waitcnt pass put an s_waitcnt vmcnt(0) into the loop body (a loop-carried "maybe pending"), and
+// that wait then also waits for the write-through stores just issued -- 0.65 us per block on the chain's critical path
+// (measured: 2.2 instead of 1.57 us per block).  These forms wait for themselves and leave nothing pending.
+__device__ __forceinline__ unsigned ld_agent_now(const unsigned *p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void st_agent_u64(unsigned long long *p, unsigned long long v) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_agent_u32(unsigned *p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void acquire_agent_now() {  // L1 invalidate, complete on return
+    asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+}
+constexpr unsigned long long kSpinTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock: every wait in here is bounded
 
 // v[l] + v[l ^ 16] in every lane
 __device__ __forceinline__ float row_pair_sum(float v) {
@@ -203,12 +238,7 @@ __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict
 // products for M21 are matrix-core work again, the first one's accumulator tile being the second one's B operand as it
 // stands.
 constexpr int kGramTabFloats = 2 * kB;  // a^d | c^d, d in [0, 64)
-constexpr int kWS = 130;                // floats per row of W in LDS: rows 16 apart land 32 banks apart
-constexpr int kGramExtFloats = kB * kWS - 2 * kH * kMS;
-__device__ __forceinline__ bool block_is_affine(const BsIteration &it, const BsBlockDesc &bd) {
-    return it.aff_min_blocks > 0 && (it.chains[bd.chain].len + kB - 1) / kB >= it.aff_min_blocks;
-}
-__device__ __forceinline__ size_t gram_tile_float4s(int nslots) { return static_cast<size_t>(kB) * (nslots | 1); }
+__host__ __device__ inline size_t gram_tile_float4s(int nslots) { return static_cast<size_t>(kB) * (nslots | 1); }
 
 __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it) {
     extern __shared__ float4 bs_smem[];
@@ -216,22 +246,34 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
     const int g = blockIdx.x;
     WaveStamp stamp(it);
     const BsBlockDesc bd = it.blocks[g];
-    if (bd.n_valid == 0) return;
+    if (bd.n_valid == 0) {
+        // The last workgroup of the grid (always an unused block: the grid is an upper bound) keeps this launch alive until
+        // every chain's workgroup of phase 2 has started: phase 3, queued behind this launch, then finds them on their CUs.
+        if (it.concurrent && g == static_cast<int>(gridDim.x) - 1 && threadIdx.x == 0 && !(it.dbg & 2)) {
+            const unsigned long long t0 = wall_clock64();
+            unsigned polls = 0;
+            while (ld_agent(it.solve_started) < it.started_target) {
+                __builtin_amdgcn_s_sleep(16);
+                if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+                    __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        return;
+    }
     const int nslots = a.nslots, RS = nslots | 1;
     float4 *tile = bs_smem;  // [kB][RS]
     float *Ms = reinterpret_cast<float *>(bs_smem + gram_tile_float4s(nslots));  // M11 | M22
     float *Ns = Ms + 2 * kH * kMS;                                                // N00 (later M21) | N11 | N10
-    float *Ws = Ns + kH * kMS;                // affine form: W [kB][kWS] takes over N11 | N10 and the extension behind
-    float *tab = Ms + 5 * kH * kMS + (it.aff_min_blocks > 0 ? kGramExtFloats : 0);
+    float *tab = Ms + 5 * kH * kMS;
     float *basev = tab + kGramTabFloats;      // [kB] r - gb - ub, 0 past the end of a short block
     const bool mine = lane < bd.n_valid;  // lane l: link l
     const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
     const int x = static_cast<int>(val >> 32);
-    const bool affine = block_is_affine(it, bd);  // workgroup uniform
     if (wave == 3) {
         // what the link's error starts from: r - gb - ub (mf_sequential.cu:119-126 without b and p.q)
         const float r0 = (__uint_as_float(static_cast<uint32_t>(val)) - a.global_bias) - a.user_bias[x];
-        if (mine) it.base[bd.pos0 + lane] = r0;
         basev[lane] = mine ? r0 : 0.f;
         tab[lane] = it.tables[kTabApow + lane];
         tab[kB + lane] = it.tables[kTabCpow + lane];
@@ -303,10 +345,6 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
     }
     __syncthreads();
     stamp.mark(it, 2);
-    if (wave != 0 && !affine) {
-        stamp.done(it, 1, 4 * g + wave);
-        return;
-    }
     if (wave == 0) {
     // M11 (lanes 0-31) and M22 (lanes 32-63): lane = column, m[kk] = M[kk][column]
     float m[kH];
@@ -338,12 +376,8 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
             }
         }
     }
-    float *Mg = it.Mbuf + static_cast<size_t>(g) * kBsFactorFloats;
 #pragma unroll
-    for (int kk = 0; kk < kH; ++kk) {
-        Mg[(h ? 2 : 0) * kH * kH + kk * kH + k] = m[kk];
-        Ms[(h * kH + kk) * kMS + k] = m[kk];
-    }
+    for (int kk = 0; kk < kH; ++kk) Ms[(h * kH + kk) * kMS + k] = m[kk];
     __builtin_amdgcn_wave_barrier();
     // T = N10 M11, then M21 = -M22 T
     f32x16 tacc, macc;
@@ -370,115 +404,33 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
         }
     }
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        Mg[kH * kH + acc_row(reg, h) * kH + k] = -macc[reg];
-        if (affine) Ns[acc_row(reg, h) * kMS + k] = -macc[reg];  // M21 where N00 was
-    }
+    for (int reg = 0; reg < 16; ++reg) Ns[acc_row(reg, h) * kMS + k] = -macc[reg];  // M21 where N00 was (its last reader is done)
     stamp.mark(it, 3);
     }  // wave 0
-    if (!affine) {
-        stamp.done(it, 1, 4 * g);
-        return;
-    }
-    // ---- affine form of the block (long chains) ------------------------------------------------------------------------
-    // state s = (item row, item bias), user rows extended by a one, Lambda = diag(a, ..., a, c):
-    //     e = M (r' - G s0),  G_k = Lambda^k (p_k, 1);   s_end = Lambda^n s0 + lr H^T e,  H_j = Lambda^(n-1-j) (p_j, 1)
-    //     =>  s_end = Lambda^n s0 - lr T' (s0, -1),  T' = H^T W,  W = M [G | r'],  e = -W (s0, -1)
-    // (tests/test_blocksolve_algebra.py, affine_chain).  W: wavefront w takes columns 32 w ..; T': wavefront w takes rows
-    // 32 w .. and all four column tiles; both contract over the 64 links in steps of two (one per lane half).
     __syncthreads();
+    // The block's record leaves the workgroup: [M11 | M21 | M22 | base], 16 bytes per lane.  In the concurrent topology
+    // WRITE-THROUGH (sc1) -- the chain's workgroup runs on another CU, usually another XCD, and is already waiting for it in this
+    // same iteration; a plain store would sit dirty in this XCD's L2 until somebody wrote the whole L2 back
+    // (MI355X_MICROARCH.md, "publish-large").
+    float *rec = it.Mbuf + static_cast<size_t>(g) * kBsRecFloats;
     {
-        const int F4 = 4 * nslots, FX = F4 + 2, TS = bs_affine_ts(nslots), RS4 = 4 * RS;
-        const float *tilef = reinterpret_cast<const float *>(tile);
-        const float *M21s = Ns;
-        const int n = bd.n_valid;
-        float *Wg = it.Wbuf + static_cast<size_t>(g) * bs_affine_w_floats(nslots);
-        float *Tg = it.Tbuf + static_cast<size_t>(g) * bs_affine_t_floats(nslots);
-        if (32 * wave < FX) {
-            const int jc = 32 * wave + k;
-            float bl[16], bu[16], m11[16], m21[16], m22[16];
+        const int t = threadIdx.x, row = t >> 3, c4 = t & 7;
+        const float *src[3] = {Ms, Ns, Ms + kH * kMS};
+        const bool through = it.concurrent && !(it.dbg & 1);  // queued behind each other, the launch boundary publishes the record
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-                const float4 x11 = *reinterpret_cast<const float4 *>(Ms + k * kMS + 16 * h + 4 * t4);
-                const float4 x22 = *reinterpret_cast<const float4 *>(Ms + (kH + k) * kMS + 16 * h + 4 * t4);
-                const float4 x21 = *reinterpret_cast<const float4 *>(M21s + k * kMS + 16 * h + 4 * t4);
-                m11[4 * t4] = x11.x, m11[4 * t4 + 1] = x11.y, m11[4 * t4 + 2] = x11.z, m11[4 * t4 + 3] = x11.w;
-                m22[4 * t4] = x22.x, m22[4 * t4 + 1] = x22.y, m22[4 * t4 + 2] = x22.z, m22[4 * t4 + 3] = x22.w;
-                m21[4 * t4] = x21.x, m21[4 * t4 + 1] = x21.y, m21[4 * t4 + 2] = x21.z, m21[4 * t4 + 3] = x21.w;
-            }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int kl = 16 * h + s, ku = kH + kl;
-                const float pl = tilef[kl * RS4 + min(jc, F4 - 1)], pu = tilef[ku * RS4 + min(jc, F4 - 1)];
-                const float cl = kl < n ? tab[kB + kl] : 0.f, cu = ku < n ? tab[kB + ku] : 0.f;
-                bl[s] = jc < F4 ? pl * tab[kl] : jc == F4 ? cl : jc == F4 + 1 ? basev[kl] : 0.f;
-                bu[s] = jc < F4 ? pu * tab[ku] : jc == F4 ? cu : jc == F4 + 1 ? basev[ku] : 0.f;
-            }
-            f32x16 wt, wb;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) wt[i] = wb[i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                wt = __builtin_amdgcn_mfma_f32_32x32x2f32(m11[s], bl[s], wt, 0, 0, 0);
-                wb = __builtin_amdgcn_mfma_f32_32x32x2f32(m21[s], bl[s], wb, 0, 0, 0);
-            }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) wb = __builtin_amdgcn_mfma_f32_32x32x2f32(m22[s], bu[s], wb, 0, 0, 0);
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int r0 = acc_row(reg, h), r1 = kH + r0;
-                Ws[r0 * kWS + jc] = wt[reg];
-                Ws[r1 * kWS + jc] = wb[reg];
-                if (jc < TS) {
-                    Wg[r0 * TS + jc] = wt[reg];
-                    Wg[r1 * TS + jc] = wb[reg];
-                }
-            }
+        for (int q = 0; q < 3; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src[q] + row * kMS + 4 * c4);
+            if (through) store_through(rec + q * kH * kH + 4 * t, v); else *reinterpret_cast<f32x4 *>(rec + q * kH * kH + 4 * t) = v;
         }
-        __syncthreads();
-        const int R = F4 + 1;
-        if (32 * wave < R) {
-            const int i = 32 * wave + k, ic = min(i, F4 - 1);
-            const int NJ = (FX + 31) >> 5;
-            f32x16 acc[4];
-#pragma unroll
-            for (int J = 0; J < 4; ++J)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[J][r] = 0.f;
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-#pragma unroll
-                for (int s4 = 0; s4 < 16; s4 += 4) {
-                    float av[4], bv[4][4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int kl = kH * kh + 16 * h + s4 + u;
-                        const int back = max(n - 1 - kl, 0);
-                        const float pv = tilef[kl * RS4 + ic];
-                        av[u] = i < F4 ? pv * tab[back] : (i == F4 && kl < n ? tab[kB + back] : 0.f);
-#pragma unroll
-                        for (int J = 0; J < 4; ++J) bv[J][u] = Ws[kl * kWS + min(32 * J + k, 127)];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                        for (int J = 0; J < 4; ++J)
-                            if (J < NJ) acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[J][u], acc[J], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int J = 0; J < 4; ++J) {
-                const int col = 32 * J + k;
-                if (J < NJ && col < TS) {
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const int row = 32 * wave + acc_row(reg, h);
-                        if (row < R) Tg[static_cast<size_t>(row) * TS + col] = acc[J][reg];
-                    }
-                }
-            }
+        if (t < kB / 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(basev + 4 * t);
+            if (through) store_through(rec + kBsFactorFloats + 4 * t, v); else *reinterpret_cast<f32x4 *>(rec + kBsFactorFloats + 4 * t) = v;
         }
+    }
+    if (it.concurrent) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's part of the record has left the CU ...
+        __syncthreads();                                   // ... and so has everybody else's: the block may be announced
+        if (threadIdx.x == 0) __hip_atomic_store(it.gram_flag + g, it.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp.done(it, 1, 4 * g + wave);
 }
@@ -512,175 +464,6 @@ __host__ __device__ inline size_t solve_lds_bytes(int nslots, int sw) {
     return (static_cast<size_t>(kRing) * solve_slot_f4(nslots) + 4 * sw + 8 + 2 * kB + 8 * kB / 4 + (kBsTableFloats + 3) / 4 + 8 + 1) * 16;
 }
 
-// ---- phase 2, long chains: the affine form ----------------------------------------------------------------------------
-// Phase 1 left T' of every block of the chain (bs_gram_kernel): the block maps the state s = (item row, item bias) to
-// Lambda^n s - lr T' (s, -1).  One wavefront applies it (lane l: rows l and 64 + l of T' against the state, broadcast
-// from LDS), three wavefronts stream the T' blocks (contiguous, (4 nslots + 1) x bs_affine_ts floats) into a ring of two
-// LDS slots, two more blocks in flight in their registers.  The start state of every block goes to phase 3, which
-// recovers the block's errors from it (e = -W (s0, -1)).
-constexpr int kRingA = 2, kDepthA = 2;
-__host__ __device__ inline int affine_block_f4(int nslots) { return (4 * nslots + 1) * ((nslots + 1) | 1); }
-__host__ __device__ inline size_t affine_lds_bytes(int nslots) {
-    return (static_cast<size_t>(kRingA) * affine_block_f4(nslots) + ((nslots + 1) | 1) + 1) * 16;
-}
-
-// a loader thread's share of block t: float4 numbers lt, lt + 192, ... (written as pack expansions: the stages must
-// stay in registers, and a loop the compiler decides not to unroll would put them in scratch memory).  Every load is
-// unconditional at a clamped address, see the loader of the other chains.
-template <int N, int... I>
-__device__ __forceinline__ void aff_issue(f32x4 (&st)[N], const float4 *Tsrc, int t, int nblk, int total4, int lt,
-                                          std::integer_sequence<int, I...>) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsrc + static_cast<size_t>(min(t, nblk - 1)) * total4);
-    ((st[I] = src[min(lt + 192 * I, total4 - 1)]), ...);
-}
-template <int N, int... I>
-__device__ __forceinline__ void aff_commit(const f32x4 (&st)[N], float4 *dst4, int total4, int lt, std::integer_sequence<int, I...>) {
-    f32x4 *dst = reinterpret_cast<f32x4 *>(dst4);
-    ((lt + 192 * I < total4 ? (void)(dst[lt + 192 * I] = st[I]) : (void)0), ...);
-}
-
-template <int SW>
-__device__ __forceinline__ void bs_affine_chain(const SgdArgs &a, const BsIteration &it, const BsChainDesc &cd, float4 *smem,
-                                                WaveStamp &stamp) {
-    constexpr int kNs = 4 * SW < 31 ? 4 * SW : 31;
-    constexpr int NA = ((4 * kNs + 1) * ((kNs + 1) | 1) + 191) / 192;  // float4 per loader thread and block
-    const int nslots = a.nslots, F4 = 4 * nslots, R = F4 + 1, n4 = (nslots + 1) | 1;
-    const int total4 = R * n4;
-    const int len = cd.len, nblk = (len + kB - 1) / kB, g0 = cd.blk0;
-    const int n_intervals = (nblk + kDepthA - 1) / kDepthA * kDepthA;
-    const int tid = threadIdx.x;
-    const float4 *Tsrc = reinterpret_cast<const float4 *>(it.Tbuf) + static_cast<size_t>(g0) * total4;
-    if (tid >= 64) {
-        const int lt = tid - 64;
-        f32x4 sa[NA], sb[NA];  // two blocks in flight
-        aff_issue(sa, Tsrc, 0, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
-        aff_issue(sb, Tsrc, 1, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
-        aff_commit(sa, smem, total4, lt, std::make_integer_sequence<int, NA>{});
-        aff_issue(sa, Tsrc, 2, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
-        __syncthreads();
-        static_assert(kDepthA == 2 && kRingA == 2, "the loop below is written out for two stages and two slots");
-        for (int m0 = 0; m0 < n_intervals; m0 += 2) {
-            aff_commit(sb, smem + total4, total4, lt, std::make_integer_sequence<int, NA>{});  // block m0 + 1
-            aff_issue(sb, Tsrc, m0 + 3, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
-            __syncthreads();
-            aff_commit(sa, smem, total4, lt, std::make_integer_sequence<int, NA>{});  // block m0 + 2
-            aff_issue(sa, Tsrc, m0 + 4, nblk, total4, lt, std::make_integer_sequence<int, NA>{});
-            __syncthreads();
-        }
-        stamp.done(it, 3, static_cast<int>(blockIdx.x) * 4 + (tid >> 6));
-        return;
-    }
-    __builtin_amdgcn_s_setprio(3);
-    const int l = tid;
-    const int y = cd.item;
-    float *sbuf = reinterpret_cast<float *>(smem + kRingA * total4);  // [4 n4]: (s, -1, 0 ...)
-    const float4 *sb4 = reinterpret_cast<const float4 *>(sbuf);
-    const int i0 = l, i1 = kB + l;
-    const int rc0 = min(i0, R - 1), rc1 = min(i1, R - 1);
-    const float q0v = a.Q[static_cast<size_t>(y) * a.ldq + min(i0, F4 - 1)], q1v = a.Q[static_cast<size_t>(y) * a.ldq + min(i1, F4 - 1)];
-    const float bv = a.item_bias[y];
-    float s0 = i0 < F4 ? q0v : i0 == F4 ? bv : 0.f;
-    float s1 = i1 < F4 ? q1v : i1 == F4 ? bv : 0.f;
-    for (int j = l; j < 4 * n4; j += 64) {
-        const float sj = j == i0 ? s0 : s1;  // j = l or 64 + l; past the state: the constant -1, then zeros
-        sbuf[j] = j <= F4 ? sj : j == F4 + 1 ? -1.f : 0.f;
-    }
-    const float lr = a.h.lr;
-    const int n_last = len - kB * (nblk - 1);
-    const float adel_full = it.tables[kTabAdel + kB], cdel_full = it.tables[kTabCdel + kB];
-    const float adel_last = it.tables[kTabAdel + n_last], cdel_last = it.tables[kTabCdel + n_last];
-    const int NC = (n4 + 3) >> 2;  // chunks of four 16-byte columns
-    __syncthreads();
-    for (int m = 0; m < n_intervals; ++m) {
-        if (m < nblk) {  // workgroup uniform
-            const bool last = m == nblk - 1;
-            const float del0 = i0 < F4 ? (last ? adel_last : adel_full) : (last ? cdel_last : cdel_full);
-            const float del1 = i1 < F4 ? (last ? adel_last : adel_full) : (last ? cdel_last : cdel_full);
-            if (i0 < F4) it.qstart[static_cast<size_t>(g0 + m) * a.ldq + i0] = s0;
-            if (i1 < F4) it.qstart[static_cast<size_t>(g0 + m) * a.ldq + i1] = s1;
-            if (i0 == F4) it.bstart[g0 + m] = s0;
-            if (i1 == F4) it.bstart[g0 + m] = s1;
-            const float4 *T4 = smem + (m % kRingA) * total4;
-            const float4 *r0 = T4 + rc0 * n4, *r1 = T4 + rc1 * n4;
-            float4 a0 = zero4(), a1 = zero4();
-            float4 ta[2][4], tb[2][4], sv[2][4];
-            auto load = [&](int buf, int ch) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = 4 * ch + i, cc = min(c, n4 - 1);
-                    ta[buf][i] = r0[cc];
-                    tb[buf][i] = r1[cc];
-                    const float4 v = sb4[cc];
-                    sv[buf][i] = c < n4 ? v : zero4();
-                }
-            };
-            auto fma8 = [&](int buf) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    a0.x = __builtin_fmaf(ta[buf][i].x, sv[buf][i].x, a0.x);
-                    a1.x = __builtin_fmaf(tb[buf][i].x, sv[buf][i].x, a1.x);
-                    a0.y = __builtin_fmaf(ta[buf][i].y, sv[buf][i].y, a0.y);
-                    a1.y = __builtin_fmaf(tb[buf][i].y, sv[buf][i].y, a1.y);
-                    a0.z = __builtin_fmaf(ta[buf][i].z, sv[buf][i].z, a0.z);
-                    a1.z = __builtin_fmaf(tb[buf][i].z, sv[buf][i].z, a1.z);
-                    a0.w = __builtin_fmaf(ta[buf][i].w, sv[buf][i].w, a0.w);
-                    a1.w = __builtin_fmaf(tb[buf][i].w, sv[buf][i].w, a1.w);
-                }
-            };
-            load(0, 0);
-            for (int ch = 0; ch < NC; ch += 2) {
-                load(1, ch + 1);  // past the last chunk: clamped addresses, zero weights
-                __builtin_amdgcn_sched_barrier(0);
-                fma8(0);
-                __builtin_amdgcn_sched_barrier(0);
-                load(0, ch + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                fma8(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const float t0 = (a0.x + a0.y) + (a0.z + a0.w), t1 = (a1.x + a1.y) + (a1.z + a1.w);
-            s0 = i0 < R ? (s0 - del0 * s0) - lr * t0 : 0.f;
-            s1 = i1 < R ? (s1 - del1 * s1) - lr * t1 : 0.f;
-            __builtin_amdgcn_wave_barrier();  // every lane has read the old state
-            if (i0 < R) sbuf[i0] = s0;
-            if (i1 < R) sbuf[i1] = s1;
-        }
-        __syncthreads();
-    }
-    if (i0 < F4) a.Q[static_cast<size_t>(y) * a.ldq + i0] = s0;
-    if (i1 < F4) a.Q[static_cast<size_t>(y) * a.ldq + i1] = s1;
-    if (i0 == F4) a.item_bias[y] = s0;
-    if (i1 == F4) a.item_bias[y] = s1;
-    stamp.done(it, 2, static_cast<int>(blockIdx.x) * 4);
-}
-
-// ---- phase 2, beside the chains: warm the solver's L2 ------------------------------------------------------------------
-// A chain is advanced by ONE CU, and what that CU can pull through the fabric (the user rows were last touched by
-// phase 1 on other XCDs) bounds the chain: about 20 GB/s measured, 37 KB a block.  Workgroups are dealt round robin over
-// the 8 XCDs, so workgroup c (chain c) and the helper workgroups n_hot_pad + 8 j + (c & 7) share an L2; the helpers
-// read the blocks of the chain (every pf_helpers-th block each) ahead of the solver and throw the data away.  If the
-// placement assumption does not hold the reads are merely useless.
-__device__ __forceinline__ void bs_warm_l2(const SgdArgs &a, const BsIteration &it, int hb) {
-    const int xcd = hb & 7, j = hb >> 3;
-    const int c = xcd + 8 * (j / it.pf_helpers), hidx = j % it.pf_helpers;
-    if (c >= it.n_hot) return;
-    const BsChainDesc cd = it.chains[c];
-    if (cd.len <= 0) return;
-    const int nblk = (cd.len + kB - 1) / kB;
-    const int t = threadIdx.x, row = t >> 2;
-    uint32_t acc = 0;
-    for (int m = hidx; m < nblk; m += it.pf_helpers) {
-        const uint64_t val = it.vals[cd.begin + min(kB * m + row, cd.len - 1)];
-        const float4 *src = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(static_cast<uint32_t>(val >> 32)) * a.ldp);
-        for (int slot = t & 3; slot < a.nslots; slot += 4) acc ^= __float_as_uint(src[slot].x);
-        const float4 *mg = reinterpret_cast<const float4 *>(it.Mbuf + static_cast<size_t>(cd.blk0 + m) * kBsFactorFloats);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc ^= __float_as_uint(mg[q * 256 + t].x);
-        if (t < kB) acc ^= __float_as_uint(it.base[cd.begin + min(kB * m + t, cd.len - 1)]);
-    }
-    asm volatile("" ::"v"(acc));  // the loads are the point
-}
-
 // The four solver wavefronts meet twice inside a block; s_barrier would drag the loaders along (their work of an interval
 // -- 25 KB of LDS writes, a few hundred cache-line requests -- would then sit on the chain's critical path), so they count
 // arrivals in LDS instead.  LDS operations of a wavefront complete in order: the partial results written before the
@@ -690,6 +473,47 @@ __device__ __forceinline__ void solvers_meet(unsigned *meet, unsigned target, in
     if (lane == 0) __hip_atomic_fetch_add(meet, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     while (__hip_atomic_load(meet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Phase 1 runs in ANOTHER launch at the same time (ordered.hip, "one iteration"): its workgroups announce every block's record
+// with a flag that carries the iteration's epoch.  Solver wavefront 0 keeps `ready` = how many leading blocks of its chain have
+// been announced and waits -- bounded: a chain whose records never arrive gives up, sets the status word and goes on with
+// undefined results, which the host reports -- until `need` are; the acquire that follows (L1 invalidate) makes the loaders' plain loads of
+// those records safe.  Once every block of the chain has been seen this costs one compare.
+__device__ __forceinline__ int await_blocks(const BsIteration &it, int g0, int nblk, int ready, int need, int lane) {
+    need = min(need, nblk);
+    if (ready >= need) return ready;
+    if (it.dbg & 4) return nblk;
+    const unsigned long long t0 = wall_clock64();
+    unsigned polls = 0;
+    for (;;) {
+        const int idx = ready + lane;
+        const unsigned v = ld_agent_now(it.gram_flag + g0 + min(idx, nblk - 1));
+        const unsigned long long mask = __ballot(idx < nblk && v == it.epoch);
+        ready += mask == ~0ull ? 64 : __ffsll(static_cast<unsigned long long>(~mask)) - 1;  // leading announced blocks
+        if (ready >= need) break;
+        __builtin_amdgcn_s_sleep(8);
+        if ((++polls & 31u) == 0 && (ld_agent_now(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+            if (lane == 0) st_agent_u32(it.status, 1u);
+            ready = nblk;
+            break;
+        }
+    }
+    acquire_agent_now();
+    return ready;
+}
+
+// waits until all but this wavefront's `newest` youngest vector-memory operations have completed (newest <= 6)
+__device__ __forceinline__ void wait_all_but(int newest) {
+    switch (newest) {  // wavefront uniform
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    }
 }
 
 // Eight wavefronts: four solvers (one per SIMD) and four loaders.
@@ -703,26 +527,15 @@ __device__ __forceinline__ void solvers_meet(unsigned *meet, unsigned target, in
 //            (the barrier is the one per block all eight wavefronts share: it hands the ring slot back to the loaders)
 //   One wavefront doing all of it issued ~500 instructions per block and took 1.35 us of the block's 1.8 us; the
 //   loaders alone sustain a block per 0.42 us (tools/build_variant.sh ablations, profiles/README.md).
-template <int SW>  // float4 slots per row quarter: 4 * SW >= nslots
-__global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it) {
-    extern __shared__ float4 bs_smem[];
-    WaveStamp stamp(it);
-    const int n_hot_pad = (it.n_hot + 7) & ~7;
-    if (static_cast<int>(blockIdx.x) >= n_hot_pad) {
-        if (threadIdx.x < 256) bs_warm_l2(a, it, static_cast<int>(blockIdx.x) - n_hot_pad);
-        stamp.done(it, 6, static_cast<int>(blockIdx.x) - n_hot_pad);
-        return;
-    }
-    if (static_cast<int>(blockIdx.x) >= it.n_hot) return;
-    const BsChainDesc cd = it.chains[blockIdx.x];
+// SW: float4 slots per row quarter (4 * SW >= nslots).  CONC: the concurrent topology's hand-over (gate, records awaited block by
+// block, write-through stores, announced progress) -- compiled out of the default, sequential instantiation, which is the plain
+// chain: its registers and its loop are not paid for by a mode it does not run (with run-time branches: 256 registers, spills).
+template <int SW, bool CONC>
+__device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration &it, float4 *bs_smem, WaveStamp &stamp, int chain) {
+    const BsChainDesc cd = it.chains[chain];
     const int begin = cd.begin, len = cd.len;
     if (len <= 0) return;  // workgroup uniform
     const int nblk = (len + kB - 1) / kB;
-    if (it.aff_min_blocks > 0 && nblk >= it.aff_min_blocks) {  // workgroup uniform
-        if (threadIdx.x >= 256) return;  // the affine form is written for four wavefronts
-        bs_affine_chain<SW>(a, it, cd, bs_smem, stamp);
-        return;
-    }
     const int g0 = cd.blk0;
     const int nslots = a.nslots, RS = nslots | 1;  // odd row stride (in float4): conflict-free ds_read_b128 down a column
     const int S4 = solve_slot_f4(nslots);
@@ -738,15 +551,22 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
         auto load_val = [&](int t) -> uint64_t { return it.vals[begin + min(kB * t + tr, len - 1)]; };
         // every load is unconditional (clamped addresses): a branch or a predicated load inside the ring would make the
         // compiler's s_waitcnt pass fall back to vmcnt(0) and serialise the ring
-        auto issue = [&](Stage<NLT> &s, int t, uint64_t val) {
+        auto issue_rows = [&](Stage<NLT> &s, int t, uint64_t val) {  // the schedule and the user rows: nothing phase 1 writes
             s.next_val = load_val(t + kDepth);
             const f32x4 *row = reinterpret_cast<const f32x4 *>(a.P + static_cast<size_t>(static_cast<uint32_t>(val >> 32)) * a.ldp);
 #pragma unroll
             for (int i = 0; i < NLT; ++i) s.rows[i] = (CU2REC_BS_ABLATE & 32) ? f32x4{0.01f, 0.01f, 0.01f, 0.01f} : row[min(tp + 4 * i, nslots - 1)];
-            const f32x4 *mg = reinterpret_cast<const f32x4 *>(it.Mbuf + static_cast<size_t>(g0 + min(t, nblk - 1)) * kBsFactorFloats);
+        };
+        auto issue_rec = [&](Stage<NLT> &s, int t) {  // phase 1's record of the block: only behind the gate / the solvers' await_blocks
+            const float *rec = it.Mbuf + static_cast<size_t>(g0 + min(t, nblk - 1)) * kBsRecFloats;
+            const f32x4 *mg = reinterpret_cast<const f32x4 *>(rec);
 #pragma unroll
             for (int q = 0; q < 3; ++q) s.m4[q] = mg[q * 256 + lt];
-            s.base = it.base[begin + min(kB * t + (lt & 63), len - 1)];
+            s.base = rec[kBsFactorFloats + (lt & 63)];
+        };
+        auto issue = [&](Stage<NLT> &s, int t, uint64_t val) {
+            issue_rows(s, t, val);
+            issue_rec(s, t);
         };
         auto commit = [&](const Stage<NLT> &s, int t) {  // block t -> ring slot t % kRing; links beyond the chain: zero rows
             f32x4 *sl = reinterpret_cast<f32x4 *>(smem + (t % kRing) * S4);
@@ -770,6 +590,11 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
             uint64_t v[kDepth];
 #pragma unroll
             for (int t = 0; t < kDepth; ++t) v[t] = load_val(t);
+            // The gate: phase 1 has announced the records of the first kDepth + 2 blocks (await_blocks).  It also guards the USER
+            // ROWS: this launch starts as soon as the previous iteration's chains are through, while that iteration's phase 3
+            // and walked chains may still be writing rows -- phase 1 of this iteration runs behind them, so a row is final once
+            // a record of this iteration exists.  (Rows fetched in front of the gate: wrong results, caught by the tests.)
+            if (CONC) __syncthreads();
 #pragma unroll
             for (int t = 0; t < kDepth; ++t) issue(st[t], t, v[t]);
             commit(st[0], 0);
@@ -786,9 +611,13 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
                 }
             }
         } else {  // everything the chain needs is requested at once
+            uint64_t v[kDepth];
+#pragma unroll
+            for (int t = 0; t < kDepth; ++t) v[t] = load_val(min(t, nblk - 1));
+            if (CONC) __syncthreads();  // the gate (see above)
 #pragma unroll
             for (int t = 0; t < kDepth; ++t)
-                if (t < nblk) issue(st[t], t, load_val(t));
+                if (t < nblk) issue(st[t], t, v[t]);
             commit(st[0], 0);
             __syncthreads();
 #pragma unroll
@@ -797,7 +626,8 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
                 __syncthreads();
             }
         }
-        stamp.done(it, 3, static_cast<int>(blockIdx.x) * 4 + ((tid >> 6) & 3));
+        stamp.done(it, 3, chain * 4 + ((tid >> 6) & 3));
+        if (CONC) __syncthreads();  // the chain is through (its solvers have stored the item row): LDS may be reused for the next one
         return;
     }
 
@@ -834,9 +664,33 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
     const float lr = a.h.lr;
     const int kr = k & 31;
     const bool upper = k >= kH;
-    __syncthreads();
+    // what a live block makes this wavefront store for phase 3 (write-through stores the compiler does not count): the
+    // errors (wavefront 0) and its share of the start row, one instruction per pass that holds any slot of the row
+    int stores_per_block = w == 0 ? 1 : 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) stores_per_block += 8 * p < SW && w * SW + 8 * p < nslots ? 1 : 0;
+    // every load of the prologue is consumed HERE, in front of the loop: a value the compiler still counts as "in flight" at the
+    // loop's head would get its s_waitcnt vmcnt(0) inside the loop body, executed every block (see ld_agent_now)
+    if (CONC) {
+        asm volatile("" ::"v"(b));
+#pragma unroll
+        for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(q4[p]));
+    }
+    int ready = 0, ops_prev = 0;
+    if (CONC && w == 0) ready = await_blocks(it, g0, nblk, 0, kDepth + 2, k);
+    if (CONC) __syncthreads();  // the gate: the loaders start
+    stamp.mark(it, 0);
+    __syncthreads();  // block 0 is in the ring
+    stamp.mark(it, 1);
+    unsigned long long *progress = it.chain_prog + chain;
     for (int m = 0; m < n_intervals; ++m) {
         const bool live = m < nblk;  // workgroup uniform
+        // Blocks [0, m - 2) have left for phase 3: at the end of block m - 1 every solver wavefront waited for its stores of the
+        // blocks before m - 2 (not for the two youngest blocks': the latency of a write-through store stays off the chain),
+        // then came the barrier.
+        const bool publish = CONC && m >= 3 && m <= nblk + 2;
+        if (tid == 0 && publish) st_agent_u64(progress, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(m - 2));
+        const int ops_now = (live && !(CU2REC_BS_ABLATE & 1) ? stores_per_block : 0) + (w == 0 && publish ? 1 : 0);
         const int n = min(kB, len - kB * m);
         const float4 *tile = smem + (m % kRing) * S4;
         const float *Mt = reinterpret_cast<const float *>(tile + kB * RS);
@@ -900,19 +754,28 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
         if (live) {
             const f32x4 e4 = lds4(epart + k);
             const float e = (e4.x + e4.y) + (e4.z + e4.w);
-            if (!(CU2REC_BS_ABLATE & 1) && w == 0 && k < n) it.ebuf[begin + kB * m + k] = e;
+            if (!(CU2REC_BS_ABLATE & 1) && w == 0) {  // the block's errors, four to a lane, write-through (phase 3 runs beside us)
+                const float e0 = k < n ? e : 0.f;
+                const f32x4 e4v = {e0, dpp_move<0x55>(e0), dpp_move<0xAA>(e0), dpp_move<0xFF>(e0)};  // quad lanes 0..3
+                if ((k & 3) == 0) {
+                    float *dst = it.ebuf + static_cast<size_t>(g0 + m) * kB + k;
+                    if (CONC) store_through(dst, e4v); else *reinterpret_cast<f32x4 *>(dst) = e4v;
+                }
+            }
             // (C) the state the block leaves behind; its start state goes to phase 3
             wbuf[k] = k < n ? lr * apr * e : 0.f;
             const float bs = row_sum16(k < n ? lr * cpr * e : 0.f);
             b = (b - cdel_n * b) + ((lane_value(bs, 0) + lane_value(bs, 16)) + (lane_value(bs, 32) + lane_value(bs, 48)));
             __builtin_amdgcn_wave_barrier();
-            f32x4 *qdst = reinterpret_cast<f32x4 *>(it.qstart + static_cast<size_t>(g0 + m) * a.ldq);
+            float *qdst = it.qstart + static_cast<size_t>(g0 + m) * a.ldq;
             const float4 *wv = reinterpret_cast<const float4 *>(wbuf) + 2 * kg;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {  // lane (slot, group): sum over the group's 8 links of w_k P[k][slot]
                 const int sq = 8 * p + sl, slot = w * SW + sq;
                 const bool ok = sq < SW && slot < nslots;
-                if (!(CU2REC_BS_ABLATE & 1) && ok && kg == 0) qdst[slot] = q4[p];
+                if (!(CU2REC_BS_ABLATE & 1) && ok && kg == 0) {
+                    if (CONC) store_through(qdst + 4 * slot, q4[p]); else *reinterpret_cast<f32x4 *>(qdst + 4 * slot) = q4[p];
+                }
                 const float4 *colp = tile + (8 * kg) * RS + min(slot, nslots - 1);
                 f32x4 tb[8], wb[2];
 #pragma unroll
@@ -940,7 +803,21 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
                 if (kg == 0 && sq < SW) *reinterpret_cast<f32x4 *>(qrow + slot) = q4[p];
             }
         }
+        // the records the loaders will ask for after the next barrier: block m + 2 + kDepth (see the loader's loop)
+        if (CONC) {
+            if (w == 0) ready = await_blocks(it, g0, nblk, ready, m + 3 + kDepth, k);
+            wait_all_but(ops_now + ops_prev);  // (never more than this wavefront really issued in the two blocks: see stores_per_block)
+            ops_prev = ops_now;
+        }
         __syncthreads();
+        if (m == nblk / 2) stamp.mark(it, 2);
+        if (m == nblk - 1) stamp.mark(it, 3);
+    }
+    if (CONC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        met += 4;
+        solvers_meet(meet, met, k);  // (the loaders have left: the workgroup barrier is not the solvers' alone any more)
+        if (tid == 0) st_agent_u64(progress, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(nblk));
     }
     if (kg == 0) {
         f32x4 *qdst = reinterpret_cast<f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
@@ -951,7 +828,24 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
         }
     }
     if (tid == 0) a.item_bias[y] = b;
-    stamp.done(it, 2, static_cast<int>(blockIdx.x) * 4 + w);
+    stamp.done(it, 2, chain * 4 + w);
+    if (CONC) __syncthreads();  // pairs with the loaders' last barrier
+}
+
+// Concurrent topology: the grid is at most half the CUs (workgroup g takes chains g, g + grid, ...: popularity ranks, so the long
+// chains come first and get a workgroup each): phase 1 runs at the same time and needs CUs of its own -- a chain's workgroup (2 x ~220
+// registers per SIMD, 80-160 KB of LDS) leaves no room for a phase-1 workgroup beside it, and chains waiting on every CU for
+// records nobody can produce would be a deadlock.  Sequential topology: one workgroup per chain.
+template <int SW, bool CONC>
+__global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it) {
+    extern __shared__ float4 bs_smem[];
+    WaveStamp stamp(it);
+    if (CONC) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // "I hold my CU"
+        for (int chain = blockIdx.x; chain < it.n_hot; chain += gridDim.x) solve_chain<SW, true>(a, it, bs_smem, stamp, chain);
+    } else if (static_cast<int>(blockIdx.x) < it.n_hot) {
+        solve_chain<SW, false>(a, it, bs_smem, stamp, blockIdx.x);
+    }
 }
 
 // ---- phase 3: the user side of every hot block ---------------------------------------------------------------------
@@ -961,7 +855,7 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
 // operand and the old value of the update, takes the new values and leaves with eight 16-byte stores per lane; errors,
 // user ids and the powers of a are read from LDS as well (a lane-dependent readlane would turn into branches).
 constexpr int kUpdStride = 36;                               // floats per tile row: 16-byte rows, 2-way conflicts at most
-constexpr int kUpdWaveFloats = kB * kUpdStride + 3 * kB;     // tile | e | user ids | partial errors (affine blocks)
+constexpr int kUpdWaveFloats = kB * kUpdStride + 2 * kB;     // tile | e | user ids
 constexpr int kUpdPowPad = 32;                               // a^d, d in [-32, 64), zero below 0
 __host__ __device__ inline size_t update_lds_bytes(int ntiles) { return (static_cast<size_t>(ntiles) * kUpdWaveFloats + kUpdPowPad + kB) * 4; }
 
@@ -975,7 +869,6 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
     WaveStamp stamp(it);
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) return;  // workgroup uniform
-    const bool affine = block_is_affine(it, bd);
     for (int i = threadIdx.x; i < kUpdPowPad + kB; i += blockDim.x) pw[i] = i < kUpdPowPad ? 0.f : it.tables[kTabApow + i - kUpdPowPad];
     float *tile = upd_smem + wave * kUpdWaveFloats;
     float *se = tile + kB * kUpdStride;
@@ -988,35 +881,29 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
     const float lr = a.h.lr;
     const int ncols = 4 * a.nslots;
     const int col = 32 * ct + c, colc = min(col, ncols - 1);
-    const float qs = it.qstart[static_cast<size_t>(g) * a.ldq + colc];
-    float e_all;
-    if (affine) {
-        // e = -W (s0, -1): lane = link, this wavefront's share of the 16-byte columns, the shares summed through LDS
-        const int nslots = a.nslots, n4 = (nslots + 1) | 1;
-        const float4 *wrow = reinterpret_cast<const float4 *>(it.Wbuf + static_cast<size_t>(g) * bs_affine_w_floats(nslots)) + lane * n4;
-        const float4 *q4 = reinterpret_cast<const float4 *>(it.qstart + static_cast<size_t>(g) * a.ldq);
-        const float b0 = it.bstart[g];
-        float part = 0.f;
-        for (int cc = ct; cc <= nslots; cc += ntiles) {
-            const float4 w4 = wrow[cc];
-            const float4 qv = q4[min(cc, nslots - 1)];
-            const float4 sv = cc < nslots ? qv : make_float4(b0, -1.f, 0.f, 0.f);
-            part = __builtin_fmaf(w4.x, sv.x, part);
-            part = __builtin_fmaf(w4.y, sv.y, part);
-            part = __builtin_fmaf(w4.z, sv.z, part);
-            part = __builtin_fmaf(w4.w, sv.w, part);
+    // The chain's workgroup (bs_solve_kernel, ANOTHER launch running beside this one) announces how many of its blocks have left
+    // for phase 3: errors and start row of block m are there once the count has passed m.  Bounded wait, then an acquire (the
+    // L1 of this CU may hold lines of ebuf / qstart that shared a cache line with something read earlier).
+    if (it.concurrent && threadIdx.x == 0 && !(it.dbg & 8)) {
+        const unsigned long long *progress = it.chain_prog + bd.chain;
+        const unsigned long long want = static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(bd.m + 1);
+        const unsigned long long t0 = wall_clock64();
+        unsigned polls = 0;
+        for (;;) {
+            const unsigned long long v = ld_agent(progress);
+            if ((v >> 32) == it.epoch && v >= want) break;
+            __builtin_amdgcn_s_sleep(48);  // ~1.3 us: hundreds of workgroups poll a few dozen words
+            if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+                __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
         }
-        float *parts = upd_smem + ct * kUpdWaveFloats + kB * kUpdStride + 2 * kB;
-        parts[lane] = part;
-        __syncthreads();
-        float sum = 0.f;
-        for (int w = 0; w < ntiles; ++w) sum += upd_smem[w * kUpdWaveFloats + kB * kUpdStride + 2 * kB + lane];
-        e_all = -sum;
-        if (ct == 0 && mine) it.ebuf[bd.pos0 + lane] = e_all;  // for the record (tests read the errors back)
-    } else {
-        e_all = it.ebuf[bd.pos0 + min(lane, bd.n_valid - 1)];
-        __syncthreads();  // the table of powers
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __syncthreads();  // (also: the table of powers)
+    const float qs = it.qstart[static_cast<size_t>(g) * a.ldq + colc];
+    const float e_all = it.ebuf[static_cast<size_t>(g) * kB + lane];
     const float e = mine ? e_all : 0.f;
     se[lane] = e;
     sx[lane] = x;
@@ -1098,11 +985,14 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
 
 template <int SW>
 void launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
-    const size_t lds = std::max(solve_lds_bytes(a.nslots, SW), it.aff_min_blocks > 0 ? affine_lds_bytes(a.nslots) : static_cast<size_t>(0));
-    ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW>));
-    const int helpers = it.pf_helpers > 0 ? 8 * it.pf_helpers * it.pf_chains : 0;
-    const int grid = helpers > 0 ? ((it.n_hot + 7) & ~7) + helpers : it.n_hot;
-    hipLaunchKernelGGL(bs_solve_kernel<SW>, dim3(grid), dim3(512), lds, stream, a, it);
+    const size_t lds = solve_lds_bytes(a.nslots, SW);
+    if (it.concurrent) {
+        ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, true>));
+        hipLaunchKernelGGL((bs_solve_kernel<SW, true>), dim3(bs_solve_grid(it.n_hot)), dim3(512), lds, stream, a, it);
+    } else {
+        ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, false>));
+        hipLaunchKernelGGL((bs_solve_kernel<SW, false>), dim3(it.n_hot), dim3(512), lds, stream, a, it);
+    }
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
         fail(CU2REC_EHIP, std::string("bs_solve_kernel launch failed: ") + hipGetErrorString(err) + " (SW " + std::to_string(SW) +
@@ -1114,6 +1004,29 @@ void launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
 namespace {
 unsigned long long *g_stamps = nullptr;
 int g_stamps_cap = 0;
+
+// One status word per device (set by a device-side wait that gave up) and its pinned host copy, refreshed after every
+// block-solve call; like the resident launches' (resident.hip).
+struct BsFault {
+    unsigned *dev_word = nullptr;
+    unsigned *host_word = nullptr;
+};
+std::mutex g_fault_mutex;
+std::vector<BsFault> g_faults;
+
+BsFault &fault_for_current_device() {  // caller holds g_fault_mutex
+    int dev = 0;
+    CU2REC_HIP(hipGetDevice(&dev));
+    if (static_cast<int>(g_faults.size()) <= dev) g_faults.resize(dev + 1);
+    BsFault &f = g_faults[dev];
+    if (!f.dev_word) {
+        CU2REC_HIP(hipMalloc(reinterpret_cast<void **>(&f.dev_word), 128));
+        CU2REC_HIP(hipMemset(f.dev_word, 0, 128));
+        CU2REC_HIP(hipHostMalloc(reinterpret_cast<void **>(&f.host_word), sizeof(unsigned), hipHostMallocDefault));
+        *f.host_word = 0;
+    }
+    return f;
+}
 }  // namespace
 
 void bs_set_stamps(unsigned long long *buf, int cap) {
@@ -1126,7 +1039,49 @@ void bs_get_stamps(unsigned long long **buf, int *cap) {
     *cap = g_stamps_cap;
 }
 
+unsigned *bs_status_word() {
+    std::lock_guard<std::mutex> lock(g_fault_mutex);
+    return fault_for_current_device().dev_word;
+}
+
+void bs_report_status(hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_fault_mutex);
+    BsFault &f = fault_for_current_device();
+    CU2REC_HIP(hipMemcpyAsync(f.host_word, f.dev_word, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+}
+
+void bs_check_fault() {
+    std::lock_guard<std::mutex> lock(g_fault_mutex);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    if (dev >= static_cast<int>(g_faults.size()) || !g_faults[dev].host_word) return;
+    BsFault &f = g_faults[dev];
+    if (*static_cast<volatile unsigned *>(f.host_word) != 0) {
+        (void)hipDeviceSynchronize();  // reported once: cleared so that the process can go on
+        (void)hipMemset(f.dev_word, 0, sizeof(unsigned));
+        *f.host_word = 0;
+        fail(CU2REC_EHIP,
+             "cu2rec_amd: a block-solve iteration gave up waiting for one of its own launches (the three phases of an iteration "
+             "run side by side and hand blocks over through flags: is another process or stream holding this GPU's compute "
+             "units?); the model state is undefined.  CU2REC_SGD_ORDERED is the same result without concurrent launches");
+    }
+}
+
 bool bs_supported(int nslots) { return nslots >= 1 && nslots <= kBsMaxSlots; }
+
+int bs_solve_grid(int n_hot) {
+    static std::mutex mutex;
+    static std::vector<int> cus;  // per device
+    int dev = 0;
+    CU2REC_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mutex);
+    if (static_cast<int>(cus.size()) <= dev) cus.resize(dev + 1, 0);
+    if (!cus[dev]) CU2REC_HIP(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
+    return std::max(1, std::min(n_hot, cus[dev] / 2));
+}
 
 void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream) {
     hipLaunchKernelGGL(bs_tables_kernel, dim3(1), dim3(128), 0, stream, h, tables);
@@ -1142,7 +1097,7 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
     const size_t gram_lds = static_cast<size_t>(kB) * (a.nslots | 1) * 16 +
-                            (static_cast<size_t>(5) * kH * kMS + (it.aff_min_blocks > 0 ? kGramExtFloats : 0) + kGramTabFloats + kB) * 4;
+                            (static_cast<size_t>(5) * kH * kMS + kGramTabFloats + kB) * 4;
     ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_gram_kernel));
     hipLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), gram_lds, stream, a, it);
     CU2REC_HIP(hipGetLastError());

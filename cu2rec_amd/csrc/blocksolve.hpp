@@ -15,6 +15,7 @@ constexpr int kBsLinks = 64;                        // updates ("links") of a ch
 constexpr int kBsTableStride = kBsLinks + 1;        // tables: 1 - a^k, 1 - c^k, a^k, c^k for k = 0..kBsLinks
 constexpr int kBsTableFloats = 4 * kBsTableStride;
 constexpr int kBsFactorFloats = 3 * 32 * 32;        // inverse factor of a block: tiles M11, M21, M22 (32 x 32 each, row major)
+constexpr int kBsRecFloats = kBsFactorFloats + kBsLinks;  // a block's record from phase 1: the factor, then r - gb - ub per link
 constexpr int kBsMaxSlots = 63;                     // float4 slots per row the solver has LDS for (n_factors <= 252)
 
 struct BsBlockDesc {  // up to 64 consecutive links of one hot chain
@@ -43,42 +44,49 @@ struct BsIteration {
     const int *item_of_rank;
     const float *tables;      // [kBsTableFloats]
     float log2a, log2c;       // log2(1 - lr * Q_reg), log2(1 - lr * item_bias_reg)
-    float *Mbuf;              // [max_blocks][kBsFactorFloats]  (I + lr L)^-1 of each block
-    float *base;              // [n_active]  r - gb - ub per hot link
-    float *ebuf;              // [n_active]  error of each hot link
-    float *qstart;            // [max_blocks][ldq]  item row at the start of each block
+    float *Mbuf;              // [max_blocks][kBsRecFloats]  (I + lr L)^-1 of each block | r - gb - ub of its links
+    float *ebuf;              // [max_blocks][kBsLinks]      error of each hot link
+    float *qstart;            // [max_blocks][ldq]           item row at the start of each block
     int max_blocks;
-    // long chains (at least aff_min_blocks blocks; 0 = none): every block's effect on the item state (row, bias) as one
-    // affine map built in phase 1, so that phase 2 is ONE mat-vec per block (blocksolve.hip, "affine form")
-    int aff_min_blocks;
-    float *Tbuf;              // [max_blocks][bs_affine_t_floats]  T' = H^T W, (4 nslots + 1) rows of bs_affine_ts floats
-    float *Wbuf;              // [max_blocks][64][bs_affine_ts]    W = M [G | r']
-    float *bstart;            // [max_blocks]  item bias at the start of each block
-    // L2 warm-up beside the chains (bs_solve_kernel): pf_helpers workgroups for each of the pf_chains longest chains of
-    // every XCD read the chain's user rows and factors ahead of its solver; 0 = none
-    int pf_helpers, pf_chains;
+    // Hand-over between the three phases, which run as three launches AT THE SAME TIME (ordered.hip): every word carries the
+    // iteration's epoch, so nothing is ever reset.
+    int concurrent;                   // 1: the phases run as launches side by side and wait for each other through the words
+                                      // below; 0 (default): they are queued one behind the other and none of this is used
+    unsigned epoch;                   // of this iteration (never 0)
+    unsigned *gram_flag;              // [max_blocks]  == epoch: phase 1 has written block g's record (write-through)
+    unsigned long long *chain_prog;   // [n_hot]       epoch << 32 | blocks of the chain whose errors / start rows have left phase 2
+    unsigned *status;                 // [1]           set by a wait that gave up (bounded spins); the host reports it
+    // Phase 3's workgroups WAIT on the device, so phase 2's must hold their CUs before phase 3 is dispatched (a CU filled with
+    // waiting phase-3 workgroups has no room for the chain they wait for).  Every phase-2 workgroup counts itself in when
+    // it starts; the last workgroup of phase 1's grid leaves only when the count has reached this iteration's target --
+    // and phase 3 is queued behind phase 1 on the same stream.
+    unsigned long long *solve_started;   // [1]  phase-2 workgroups started, over all iterations so far
+    unsigned long long started_target;   //      ... including all of this iteration's
     // development aid (cu2rec_debug_blocksolve_stamps): [0] = entries appended so far, then {kernel, id, start, end}
     // per wavefront in units of the 100 MHz s_memrealtime clock; nullptr in normal operation
     unsigned long long *stamps;
     int stamps_cap;
+    int dbg;  // CU2REC_BS_DBG, timing experiments only (results undefined): 1 plain stores in phase 1, 2 phase 1 does not wait for
+              // phase 2's start, 4 phase 2 does not wait for records, 8 phase 3 does not wait for progress
 };
 
 // process-wide stamp buffer for the launches that follow (nullptr = off)
 void bs_set_stamps(unsigned long long *buf, int cap);
 void bs_get_stamps(unsigned long long **buf, int *cap);
 bool bs_supported(int nslots);
-// the affine form needs the state (row, bias) and the constant column inside 128 columns: n_factors <= 124
-__host__ __device__ inline bool bs_affine_supported(int nslots) { return nslots <= 31; }
-// floats per row of T' and W: the columns 4 nslots + 2, in 16-byte pieces, an odd number of them (LDS bank spread)
-__host__ __device__ inline int bs_affine_ts(int nslots) { return 4 * ((nslots + 1) | 1); }
-__host__ __device__ inline size_t bs_affine_t_floats(int nslots) { return static_cast<size_t>(4 * nslots + 1) * bs_affine_ts(nslots); }
-__host__ __device__ inline size_t bs_affine_w_floats(int nslots) { return static_cast<size_t>(kBsLinks) * bs_affine_ts(nslots); }
+int bs_solve_grid(int n_hot);  // workgroups of phase 2: one per chain, at most half the CUs of the current device
+// bounded device-side waits report through one status word per device: its address, an asynchronous refresh of the host copy
+// behind a call's launches, and the check (throws CU2REC_EHIP once if a wait gave up)
+unsigned *bs_status_word();
+void bs_report_status(hipStream_t stream);
+void bs_check_fault();
 void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream);
 // one workgroup per iteration of the batch: chain and block descriptors
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
                     const int *item_of_rank, int *chain_begin, BsChainDesc *chains, BsBlockDesc *blocks, int *walk_begin,
                     hipStream_t stream);
-// the three phases of one iteration's hot chains, in this order on one stream
+// the three phases of one iteration's hot chains: three launches that may run at the same time on three streams (phase 2 waits
+// for phase 1's records block by block, phase 3 for phase 2's progress chain by chain, through the words above)
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
 void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
 void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream);

@@ -14,6 +14,13 @@
 
 namespace cu2rec {
 
+// what a persistent / concurrent launch could not finish is reported at the next entry point (resident.hip, blocksolve.hip)
+static void check_faults() {
+    resident_check_fault();
+    bs_check_fault();
+}
+
+
 namespace {
 
 hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
@@ -93,7 +100,7 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
                               n_factors, hyper, seed, update_items, user_offset);
     if (n_rows == 0 || n_iters == 0) return;
     require_device();
-    resident_check_fault();
+    check_faults();
     require((reinterpret_cast<uintptr_t>(sample_pairs) & 7u) == 0, "cu2rec_sgd_update: sample pairs must be 8-byte aligned");
     a.pairs = static_cast<const uint2 *>(sample_pairs);
     if (mode == CU2REC_SGD_SERIAL) {
@@ -132,7 +139,7 @@ bool sgd_update_pingpong(const int *indptr, const int *indices, const float *dat
                               n_factors, hyper, seed, update_items, user_offset);
     if (n_rows == 0 || n_iters == 0) return false;
     require_device();
-    resident_check_fault();
+    check_faults();
     // claims carry the iteration number; a call may restart from an earlier one, so they start from "nobody"
     CU2REC_HIP(hipMemsetAsync(claim, 0xFF, static_cast<size_t>(std::max(n_cols, 1)) * sizeof(unsigned long long), stream));
     PingPongArgs pp{Q_target, item_bias_target, claim};
@@ -179,7 +186,7 @@ void sgd_update_ordered(OrderedSchedule &schedule, const int *indptr, const int 
                               n_factors, hyper, seed, update_items, user_offset);
     if (n_rows == 0 || n_iters == 0) return;
     require_device();
-    resident_check_fault();
+    check_faults();
     schedule.run(a, iter0, n_iters, stream, blocksolve);
 }
 
@@ -197,7 +204,7 @@ void loss(const int *indptr, const int *indices, const float *data, int n_rows, 
         check_aligned(P, "P");
         check_aligned(Q, "Q");
         require_device();
-        resident_check_fault();
+        check_faults();
         LossArgs a{};
         a.indptr = indptr;
         a.indices = indices;
@@ -218,7 +225,7 @@ void loss(const int *indptr, const int *indices, const float *data, int n_rows, 
         launch_loss(a, blocks, stream);
         CU2REC_HIP(hipGetLastError());
         s = collect_partials(a.partials, blocks, stream);
-        resident_check_fault();  // the stream has been drained: a resident launch before this pass has reported by now
+        check_faults();  // the stream has been drained: a resident launch before this pass has reported by now
     }
     if (sum_abs) *sum_abs = s.sum_abs;
     if (sum_sq) *sum_sq = s.sum_sq;
@@ -314,7 +321,7 @@ DeviceModel::DeviceModel(int rows_, int cols_, int f_, const float *hP, const fl
 void DeviceModel::download(float *hP, float *hQ, float *hub, float *hib) const {
     require(!swap_pending, "cu2rec_model_download: a ping-pong swap is pending (finish_swap)");
     CU2REC_HIP(hipDeviceSynchronize());
-    resident_check_fault();
+    check_faults();
     if (hP) download_padded(P, hP, rows, n_factors, ld);
     if (hQ) download_padded(Q, hQ, cols, n_factors, ldq);
     if (hub && rows) user_bias.download(hub, rows);
@@ -491,7 +498,7 @@ int cu2rec_check_faults(void) {
     return guarded([&] {
         require_device();
         CU2REC_HIP(hipDeviceSynchronize());
-        resident_check_fault();
+        check_faults();
     });
 }
 
@@ -562,8 +569,6 @@ int cu2rec_csr_blocksolve_items(const cu2rec_csr *train) {
     });
     return rc == CU2REC_OK ? n : -1;
 }
-
-int cu2rec_blocksolve_affine_blocks(int blocks) { return blocksolve_affine_blocks(blocks); }
 
 int cu2rec_debug_blocksolve_stamps(void *buffer, int capacity) {
     return guarded([&] {

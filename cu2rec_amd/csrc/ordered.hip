@@ -634,24 +634,32 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         CU2REC_HIP(hipEventCreateWithFlags(&ev_consumed[slot], hipEventDisableTiming));
     }
     tables.allocate(kBsTableFloats);
+    CU2REC_HIP(hipEventCreateWithFlags(&ev_last, hipEventDisableTiming));
     if (n_hot_bs > 0) {
-        Mbuf.allocate(static_cast<size_t>(max_blocks) * kBsFactorFloats);
-        basebuf.allocate(std::max(n_active, 1));
-        ebuf.allocate(std::max(n_active, 1));
+        Mbuf.allocate(static_cast<size_t>(max_blocks) * kBsRecFloats);
+        ebuf.allocate(static_cast<size_t>(max_blocks) * kBsLinks);
+        gram_flag.allocate(max_blocks);
+        gram_flag.zero();  // epochs start at 1
+        chain_prog.allocate(n_hot_bs);
+        chain_prog.zero();
+        solve_started.allocate(16);
+        solve_started.zero();
     }
 }
 
 OrderedSchedule::~OrderedSchedule() {
+    // queued work may still read the buffers this object owns
+    if (have_last) (void)hipEventSynchronize(ev_last);
+    if (sched) (void)hipStreamSynchronize(sched);
     if (sched) (void)hipStreamDestroy(sched);
     for (int slot = 0; slot < 2; ++slot) {
         if (ev_ready[slot]) (void)hipEventDestroy(ev_ready[slot]);
         if (ev_consumed[slot]) (void)hipEventDestroy(ev_consumed[slot]);
     }
-    if (side) (void)hipStreamDestroy(side);
-    if (side2) (void)hipStreamDestroy(side2);
-    if (ev_join2) (void)hipEventDestroy(ev_join2);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (solve) (void)hipStreamDestroy(solve);
+    if (upd) (void)hipStreamDestroy(upd);
+    for (hipEvent_t e : {ev_call, ev_upd, ev_solve, ev_gram, ev_last})
+        if (e) (void)hipEventDestroy(e);
 }
 
 namespace {
@@ -688,25 +696,12 @@ float blocksolve_min_rate(float rate) {
     return prev > 0.f ? prev : -1.f;
 }
 
-namespace {
-std::atomic<int> g_bs_affine_blocks{-1};
-}
-
-int blocksolve_affine_blocks(int blocks) {
-    int prev = g_bs_affine_blocks.load();
-    if (prev < 0) {  // first use: off (measured slower than the plain form), CU2REC_BLOCKSOLVE_AFFINE overrides
-        int init = 0;
-        if (const char *env = std::getenv("CU2REC_BLOCKSOLVE_AFFINE")) init = std::max(0, std::atoi(env));
-        g_bs_affine_blocks.compare_exchange_strong(prev, init);
-        prev = g_bs_affine_blocks.load();
-    }
-    if (blocks >= 0) g_bs_affine_blocks.store(blocks);
-    return prev;
-}
-
 void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream, bool blocksolve) {
     if (n_active == 0) return;
     if (blocksolve && n_hot_bs == 0) blocksolve = false;  // nothing to solve block-wise: the ordered walk, bit for bit
+    // The workspace (key / value buffers, block records, events) exists once: a call on another stream than the last one
+    // starts behind that call's end.
+    if (have_last && last_stream != stream) CU2REC_HIP(hipStreamWaitEvent(stream, ev_last, 0));
     if (blocksolve) {
         if (!bs_supported(a.nslots)) fail(CU2REC_EUNSUPPORTED, "block-solve mode is compiled for n_factors <= 252");
         const bool same = tables_valid && tables_for.lr == a.h.lr && tables_for.q_reg == a.h.q_reg && tables_for.ib_reg == a.h.ib_reg;
@@ -715,44 +710,18 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             tables_for = a.h;
             tables_valid = true;
         }
-        if (n_hot_bs > 0 && qstart_ld != a.ldq) {
+        if (qstart_ld != a.ldq) {
             CU2REC_HIP(hipStreamSynchronize(stream));
             qstart.allocate(static_cast<size_t>(max_blocks) * a.ldq);
             qstart_ld = a.ldq;
         }
-        aff_min_blocks = bs_affine_supported(a.nslots) ? blocksolve_affine_blocks(-1) : 0;
-        pf_helpers = 0, pf_chains = 0;  // measured: no gain (the loaders are not what bounds a chain), DESIGN.md section 4
-        if (const char *env = std::getenv("CU2REC_BS_PREFETCH")) {  // "helpers,chains": tuning aid
-            if (std::sscanf(env, "%d,%d", &pf_helpers, &pf_chains) != 2) pf_helpers = pf_chains = 0;
-            pf_helpers = std::max(0, std::min(pf_helpers, 16));
-            pf_chains = std::max(0, std::min(pf_chains, 8));
-            if (pf_chains == 0) pf_helpers = 0;
-        }
-        if (n_hot_bs > 0 && aff_min_blocks > 0 && affine_nslots != a.nslots) {
-            CU2REC_HIP(hipStreamSynchronize(stream));
-            Tbuf.allocate(static_cast<size_t>(max_blocks) * bs_affine_t_floats(a.nslots));
-            Wbuf.allocate(static_cast<size_t>(max_blocks) * bs_affine_w_floats(a.nslots));
-            bstart.allocate(max_blocks);
-            affine_nslots = a.nslots;
-        }
-        if (!side) {
-            // The chains solved block-wise are the iteration's critical path; what runs beside them gets the lowest
-            // stream priority.  (A CU-masked side stream was tried: three CUs out of four for the walked chains made
-            // an iteration 100 us longer, 273 against 167 us.)
-            int lo = 0, hi = 0;
-            CU2REC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            if (std::getenv("CU2REC_BS_SIDE_PLAIN")) lo = hi = 0;
-            if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess) {
-                (void)hipGetLastError();
-                CU2REC_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-            }
-            if (hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, lo) != hipSuccess) {
-                (void)hipGetLastError();
-                CU2REC_HIP(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
-            }
-            CU2REC_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
-            CU2REC_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-            CU2REC_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        if (!solve) {
+            // default priorities all round: a high-priority queue whose workgroups cannot all be placed (more hot chains than
+            // CUs) held back the queues below it, including phase 1, which those workgroups wait for (a 300-chain test set
+            // ran into the waits' timeout)
+            CU2REC_HIP(hipStreamCreateWithFlags(&solve, hipStreamNonBlocking));
+            CU2REC_HIP(hipStreamCreateWithFlags(&upd, hipStreamNonBlocking));
+            for (hipEvent_t *e : {&ev_call, &ev_upd, &ev_solve, &ev_gram}) CU2REC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
     }
     const uint32_t item_mask = (1u << item_bits) - 1u;
@@ -805,6 +774,12 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         schedule(0, iter0, nb_first);
     }
     spec.valid = false;
+    if (blocksolve) {  // the other two streams of the mode start behind everything the caller has queued so far
+        CU2REC_HIP(hipEventRecord(ev_call, stream));
+        CU2REC_HIP(hipStreamWaitEvent(solve, ev_call, 0));
+        CU2REC_HIP(hipStreamWaitEvent(upd, ev_call, 0));
+    }
+    bool upd_pending = false;  // phase 3 of an earlier iteration of THIS call has not been waited for by `stream` yet
     int done = 0;
     for (int j = 0; j < n_batches; ++j) {
         const int slot = (base_slot + j) & 1;
@@ -821,10 +796,28 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         const uint64_t *sv = ready[slot].sv;
         a.iters = 1;
         if (blocksolve) {
+            // One iteration = four launches: phase 1 (bs_gram_kernel: every block's inverse factor), phase 2 (bs_solve_kernel: one
+            // workgroup per chain), phase 3 (bs_update_kernel: the user side), and the other items' chains (two-wave form / walk).
+            // The kernels hand blocks over through device words tagged with the iteration's epoch (blocksolve.hpp), so they are
+            // correct in EITHER launch topology:
+            //  * sequential (default): `stream`: phase 1 -> phase 2 -> phase 3; second stream: the other chains, forked behind
+            //    phase 1 and joined in front of the next phase 1.  Every producer has finished before its consumer starts: the
+            //    device-side waits fall through.
+            //  * concurrent (CU2REC_BS_CONCURRENT=1, opt-in): `stream`: phase 1 -> the other chains; `solve`: phase 2, which
+            //    starts on a block as soon as phase 1 has announced it; second stream: phase 3 behind phase 1, its workgroups
+            //    waiting chain by chain for phase 2's progress.  Measured at parity with the sequential topology (DESIGN.md
+            //    section 4: the chain stays the critical path) and it NEEDS the three streams to be three hardware queues -- the
+            //    HIP runtime multiplexes streams onto a small pool of queues, and two of these launches in one queue would wait
+            //    for each other until the bounded waits give up -- so it is not the default.
+            static const bool concurrent = std::getenv("CU2REC_BS_CONCURRENT") != nullptr && std::atoi(std::getenv("CU2REC_BS_CONCURRENT")) != 0;
+            if (concurrent) CU2REC_HIP(hipStreamWaitEvent(solve, ev_ready[slot], 0));
+            CU2REC_HIP(hipStreamWaitEvent(upd, ev_ready[slot], 0));
             const double la = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.q_reg));
             const double lc = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.ib_reg));
+            unsigned *status = bs_status_word();
             for (int b = 0; b < nb; ++b) {
                 a.iter0 = iter0 + done + b;
+                if (++bs_epoch == 0) ++bs_epoch;
                 BsIteration it{};
                 it.keys = sk + static_cast<size_t>(b) * n_active;
                 it.vals = sv + static_cast<size_t>(b) * n_active;
@@ -839,53 +832,68 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.log2a = static_cast<float>(la);
                 it.log2c = static_cast<float>(lc);
                 it.Mbuf = Mbuf.ptr;
-                it.base = basebuf.ptr;
                 it.ebuf = ebuf.ptr;
                 it.qstart = qstart.ptr;
                 it.max_blocks = max_blocks;
-                it.aff_min_blocks = aff_min_blocks;
-                it.pf_helpers = pf_helpers;
-                it.pf_chains = pf_chains;
-                it.Tbuf = Tbuf.ptr;
-                it.Wbuf = Wbuf.ptr;
-                it.bstart = bstart.ptr;
+                it.concurrent = concurrent ? 1 : 0;
+                it.epoch = bs_epoch;
+                it.gram_flag = gram_flag.ptr;
+                it.chain_prog = chain_prog.ptr;
+                it.status = status;
+                it.solve_started = solve_started.ptr;
                 bs_get_stamps(&it.stamps, &it.stamps_cap);
-                // The other chains touch other items and other users than the hot ones: fork, run beside, join.  The fork
-                // sits behind phase 1 and the chains' launch comes first: workgroups of the side kernel that already
-                // fill the CUs would keep the chains' workgroups (80 KB of LDS each) waiting, and those are the
-                // iteration's critical path (measured: the chains started 17 us late with the fork in front of phase 1).
-                static const bool fork_early = std::getenv("CU2REC_BS_FORK_EARLY") != nullptr;  // tuning aid
-                if (fork_early) {
-                    CU2REC_HIP(hipEventRecord(ev_fork, stream));
-                    CU2REC_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+                static const int dbg = std::getenv("CU2REC_BS_DBG") ? std::atoi(std::getenv("CU2REC_BS_DBG")) : 0;  // timing experiments
+                it.dbg = dbg;
+                if (!concurrent) {
+                    it.started_target = 0;  // phase 2 is queued behind phase 1: nothing to wait for
+                    if (upd_pending) {  // join: the previous iteration's other chains may have written rows phase 1 reads
+                        CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));
+                    }
+                    bs_launch_gram(a, it, stream);
+                    // The other chains touch other items and other users than the hot ones: fork, run beside, join.  The fork
+                    // sits behind phase 1: workgroups of the side kernel that already fill the CUs would keep phase 1's waiting
+                    // (measured: 71 instead of 19 us).
+                    CU2REC_HIP(hipEventRecord(ev_gram, stream));
+                    CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
+                    bs_launch_solve(a, it, stream);
+                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, static_cast<uint32_t>(b) << item_bits,
+                                  std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs);
+                    CU2REC_HIP(hipEventRecord(ev_upd, upd));
+                    bs_launch_update(a, it, stream);
+                    upd_pending = true;
+                    continue;
+                }
+                // phase 2 first: its few workgroups take their CUs before anything else of this iteration asks for room
+                started_total += static_cast<unsigned long long>(bs_solve_grid(n_hot_bs));
+                it.started_target = started_total;
+                bs_launch_solve(a, it, solve);
+                // phase 1 reads user rows the previous iteration's phase 3 may have written
+                if (upd_pending) {
+                    CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));
                 }
                 bs_launch_gram(a, it, stream);
-                if (!fork_early) {
-                    CU2REC_HIP(hipEventRecord(ev_fork, stream));
-                    CU2REC_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-                }
-                bs_launch_solve(a, it, stream);
-                // ranks [n_hot_bs, n_duo_bs): the ordered mode's two-wave chains; beyond: its windowed walk
-                // (the walk as a launch of its own on a third stream -- inside sgd_ordered_kernel every block reserves the
-                // two-wave role's 33 KB of LDS -- was measured: both launches take ~50 us, the extra events cost 16 us)
-                static const bool split_walk = std::getenv("CU2REC_BS_SPLIT_WALK") != nullptr;  // tuning aid
-                if (split_walk) {
-                    CU2REC_HIP(hipStreamWaitEvent(side2, ev_fork, 0));
-                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask,
-                                  static_cast<uint32_t>(b) << item_bits, std::max(n_duo_bs, n_hot_bs), side, n_hot_bs, kRoleDuo);
-                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask,
-                                  static_cast<uint32_t>(b) << item_bits, std::max(n_duo_bs, n_hot_bs), side2, n_hot_bs, kRoleWalk);
-                    CU2REC_HIP(hipEventRecord(ev_join2, side2));
-                } else {
-                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask,
-                                  static_cast<uint32_t>(b) << item_bits, std::max(n_duo_bs, n_hot_bs), side, n_hot_bs);
-                }
-                CU2REC_HIP(hipEventRecord(ev_join, side));
-                bs_launch_update(a, it, stream);
-                CU2REC_HIP(hipStreamWaitEvent(stream, ev_join, 0));
-                if (split_walk) CU2REC_HIP(hipStreamWaitEvent(stream, ev_join2, 0));
+                CU2REC_HIP(hipEventRecord(ev_gram, stream));
+                // The other chains (ranks [n_hot_bs, n_duo_bs): the ordered mode's two-wave form; beyond: its walk): other items,
+                // other users.  On the SAME stream, behind phase 1: beside it their thousands of workgroups take the CUs away from
+                // phase 1's (measured: 71 instead of 19 us), and a cross-stream edge costs 13-14 us each way on this runtime
+                // (phase 1 -> other chains -> next phase 1 on two streams: 106 us per iteration, 27 of them event latency).
+                launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, static_cast<uint32_t>(b) << item_bits,
+                              std::max(n_duo_bs, n_hot_bs), stream, n_hot_bs);
+                // phase 3 on a stream of its own, behind phase 1 (hence behind the previous iteration's other chains, whose rows
+                // it may rewrite, and behind the start of every phase-2 workgroup): its workgroups wait for the chains' progress
+                CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
+                bs_launch_update(a, it, upd);
+                CU2REC_HIP(hipEventRecord(ev_upd, upd));
+                upd_pending = true;
             }
             CU2REC_HIP(hipGetLastError());
+            // the batch's slot is free once all three streams are through with it
+            if (concurrent) {
+                CU2REC_HIP(hipEventRecord(ev_solve, solve));
+                CU2REC_HIP(hipStreamWaitEvent(stream, ev_solve, 0));
+            }
+            CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));
+            upd_pending = false;  // (waited for)
             CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));
             done += nb;
             continue;
@@ -901,6 +909,10 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));
         done += nb;
     }
+    if (blocksolve) bs_report_status(stream);  // (every batch ended with `stream` behind the other two streams)
+    CU2REC_HIP(hipEventRecord(ev_last, stream));
+    last_stream = stream;
+    have_last = true;
 }
 
 }  // namespace cu2rec

@@ -59,14 +59,21 @@ struct OrderedSchedule {
     DeviceBuffer<int> chain_begin[2], walk_begin[2];
     DeviceBuffer<BsChainDesc> bs_chains[2];
     DeviceBuffer<BsBlockDesc> bs_blocks[2];
-    DeviceBuffer<float> tables, Mbuf, basebuf, ebuf, qstart;
-    DeviceBuffer<float> Tbuf, Wbuf, bstart;  // affine form of the long chains (blocksolve.hip); sized on first use
-    int affine_nslots = 0;
-    int aff_min_blocks = 0;  // of the run in progress
-    int pf_helpers = 0, pf_chains = 0;
-    hipStream_t side = nullptr;            // the two-wave chains of an iteration run beside its three phases
-    hipStream_t side2 = nullptr;           // ... and so does the walk of the short chains, as a launch of its own
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    DeviceBuffer<float> tables, Mbuf, ebuf, qstart;
+    // Block-solve mode: an iteration is four launches on three streams that run side by side -- `stream` (the caller's): phase 1,
+    // then the other items' chains (two-wave form + walk); `solve`: phase 2; `upd`: phase 3, behind phase 1 (ev_gram).  Phase 2
+    // waits for phase 1 block by block and phase 3 for phase 2 chain by chain through device words tagged with the iteration's
+    // epoch (blocksolve.hpp); one event edge per iteration crosses back: phase 3 of iteration i before phase 1 of i + 1 (ev_upd).
+    DeviceBuffer<unsigned> gram_flag;
+    DeviceBuffer<unsigned long long> chain_prog, solve_started;
+    unsigned long long started_total = 0;  // phase-2 workgroups launched so far (what solve_started will reach)
+    unsigned bs_epoch = 0;
+    hipStream_t solve = nullptr, upd = nullptr;
+    hipEvent_t ev_call = nullptr, ev_upd = nullptr, ev_solve = nullptr, ev_gram = nullptr;
+    // one stream at a time per schedule: a call on another stream than the last one first waits for that call's end
+    hipEvent_t ev_last = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
     ~OrderedSchedule();
 };
 
@@ -76,7 +83,5 @@ struct OrderedSchedule {
 float blocksolve_min_rate(float rate);
 float blocksolve_min_rate_base();   // the explicit value, or the default the automatic scaling starts from
 bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwise a schedule scales the default with its set
-// chains of at least this many blocks of 64 links take the affine form (0: none); blocks < 0 only queries
-int blocksolve_affine_blocks(int blocks);
 
 }  // namespace cu2rec

@@ -281,13 +281,6 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
  * rate > 0 sets an explicit threshold, rate < 0 returns to the automatic one, rate == 0 only queries.  Returns what was in
  * force before the call: the explicit threshold, or -1 for automatic (so passing a returned value back restores it). */
 float cu2rec_blocksolve_min_rate(float rate);
-/* Chains of at least `blocks` blocks of 64 updates (one item, one iteration) are advanced in the affine form: phase 1
- * also builds, per block, the matrix that maps the item's row and bias at the start of the block to those at its end,
- * and the chain itself is one matrix-vector product per block (n_factors <= 124; wider rows keep the plain form).
- * Process-wide, read at every SGD call; default 0 = off: on MI355X the form measured slower than the plain one (one CU
- * streams a 43 KB matrix per block at about 15 GB/s); CU2REC_BLOCKSOLVE_AFFINE overrides.
- * Returns the previous value; blocks < 0 only queries. */
-int cu2rec_blocksolve_affine_blocks(int blocks);
 /* Development aid: while `buffer` (device memory, 8 * (1 + 8 * capacity) bytes, zeroed by the caller) is set, every
  * wavefront of the block-solve kernels writes {kernel, id, start, end, 4 marks (trace builds)} in ticks of the 100 MHz device clock into record
  * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 5 walk; records never written stay

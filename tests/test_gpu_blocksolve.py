@@ -61,26 +61,6 @@ def test_blocksolve_matches_sequential_oracle(min_rate, users, items, nnz, f, it
     assert max(diffs) <= 2e-6, diffs  # float rounding of re-associated sums; values are O(0.1 .. 1)
 
 
-@pytest.mark.parametrize("users,items,nnz,f,iters,rate,aff", [
-    (300, 120, 6000, 10, 70, 2.0, 1),     # every hot chain in the affine form
-    (3000, 40, 30000, 100, 6, 1.0, 1),    # three blocks a chain, the last one partial
-    (9000, 6, 40000, 100, 3, 1.0, 10),    # ~24 blocks a chain: the ring of T' blocks
-    (9000, 6, 40000, 124, 3, 1.0, 2),     # the widest row the form takes (state + constant column = 126 <= 128)
-    (2000, 300, 40000, 128, 5, 0.5, 1),   # wider: falls back to the plain form
-    (9000, 12, 60000, 40, 4, 1.0, 8),     # mixed: chains on both sides of the threshold
-])
-def test_blocksolve_affine_form_matches_sequential_oracle(min_rate, users, items, nnz, f, iters, rate, aff):
-    """cu2rec_blocksolve_affine_blocks: the opt-in form that advances a long chain with one mat-vec per block."""
-    min_rate(rate)
-    prev = cu.api.blocksolve_affine_blocks(aff)
-    try:
-        tr, _ = synth.make_ratings(users, items, nnz, min_degree=3, seed=users + f)
-        model, state = _run_both(tr, f, iters)
-        assert max(_max_diffs(model, state)) <= 2e-6
-    finally:
-        cu.api.blocksolve_affine_blocks(prev)
-
-
 def test_blocksolve_without_hot_items_is_the_ordered_walk_bit_for_bit(min_rate):
     min_rate(1e9)
     tr, _ = synth.make_ratings(3000, 40, 30000, min_degree=3, seed=11)
