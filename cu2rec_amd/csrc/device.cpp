@@ -44,16 +44,19 @@ struct PartialSums {
     double sum_abs = 0.0, sum_sq = 0.0;
 };
 
-PartialSums collect_partials(const double *device_partials, int blocks, hipStream_t stream) {
-    thread_local std::vector<double> host;
-    host.resize(static_cast<size_t>(2) * blocks);
-    CU2REC_HIP(hipMemcpyAsync(host.data(), device_partials, host.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+// The per-block partial sums are added ON THE DEVICE (one more tiny launch, 6 us) and two doubles come back, into pinned memory:
+// the reference copies every block's partial sum back and adds them on the host, twice per metric pair (loss.cu:183-190), and
+// so did rounds 1-2 here (64 KB through a pageable staging copy).
+PartialSums collect_partials(double *device_partials, int blocks, hipStream_t stream) {
+    thread_local double *pinned = nullptr;
+    if (!pinned) CU2REC_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), 2 * sizeof(double), hipHostMallocDefault));
+    launch_partials_reduce(device_partials, blocks, stream);
+    CU2REC_HIP(hipGetLastError());
+    CU2REC_HIP(hipMemcpyAsync(pinned, device_partials + 2 * kMaxPartialBlocks, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));
     CU2REC_HIP(hipStreamSynchronize(stream));
     PartialSums s;
-    for (int b = 0; b < blocks; ++b) {
-        s.sum_abs += host[2 * b];
-        s.sum_sq += host[2 * b + 1];
-    }
+    s.sum_abs = pinned[0];
+    s.sum_sq = pinned[1];
     return s;
 }
 
@@ -315,7 +318,7 @@ DeviceModel::DeviceModel(int rows_, int cols_, int f_, const float *hP, const fl
     item_bias.allocate(std::max(cols, 1));
     if (rows) user_bias.upload(init_if_null(hub, rows), rows);
     if (cols) item_bias.upload(init_if_null(hib, cols), cols);
-    workspace.allocate(static_cast<size_t>(2) * kMaxPartialBlocks);
+    workspace.allocate(static_cast<size_t>(2) * kMaxPartialBlocks + 2);
 }
 
 void DeviceModel::download(float *hP, float *hQ, float *hub, float *hib) const {
@@ -577,7 +580,7 @@ int cu2rec_debug_blocksolve_stamps(void *buffer, int capacity) {
     });
 }
 
-size_t cu2rec_loss_workspace_bytes(void) { return sizeof(double) * 2 * kMaxPartialBlocks; }
+size_t cu2rec_loss_workspace_bytes(void) { return sizeof(double) * (2 * kMaxPartialBlocks + 2); }
 
 int cu2rec_loss(const int *indptr, const int *indices, const float *data, int n_rows, int nnz, const float *P, int ldp,
                 const float *Q, int ldq, const float *user_bias, const float *item_bias, float global_bias,

@@ -453,6 +453,38 @@ void launch_loss(const LossArgs &a, int blocks, hipStream_t stream) {
     }
 }
 
+namespace {
+// ---- the per-block partial sums of a loss pass -> two numbers, on the device (loss.cu:185-190 adds them on the host behind a
+// blocking copy of all of them): one workgroup, thread t adds partials t, t + 256, ... in that order, then a guarded tree; fixed
+// order, hence the same bits run after run.  out = partials + 2 * kMaxPartialBlocks: {sum |e|, sum e^2}.
+__global__ __launch_bounds__(kBlock) void partials_reduce_kernel(const double *__restrict__ partials, int blocks, double *__restrict__ out) {
+    __shared__ double s_abs[kBlock], s_sq[kBlock];
+    double sa = 0.0, ss = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += kBlock) {
+        sa += partials[2 * b];
+        ss += partials[2 * b + 1];
+    }
+    s_abs[threadIdx.x] = sa;
+    s_sq[threadIdx.x] = ss;
+    __syncthreads();
+    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
+        if (static_cast<int>(threadIdx.x) < stride) {
+            s_abs[threadIdx.x] += s_abs[threadIdx.x + stride];
+            s_sq[threadIdx.x] += s_sq[threadIdx.x + stride];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = s_abs[0];
+        out[1] = s_sq[0];
+    }
+}
+}  // namespace
+
+void launch_partials_reduce(double *partials, int blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(partials_reduce_kernel, dim3(1), dim3(kBlock), 0, stream, partials, blocks, partials + 2 * kMaxPartialBlocks);
+}
+
 int error_metrics_blocks(int n) { return blocks_for(static_cast<size_t>(n), kBlock * 4, kMaxPartialBlocks); }
 
 void launch_error_metrics(const float *errors, int n, double *partials, int blocks, hipStream_t stream) {

@@ -71,6 +71,9 @@ void launch_sgd(const SgdArgs &args, int mode, hipStream_t stream);
 void launch_sgd_pingpong(const SgdArgs &args, const PingPongArgs &pp, hipStream_t stream);
 int loss_blocks(int nnz);
 void launch_loss(const LossArgs &args, int blocks, hipStream_t stream);
+// {sum |e|, sum e^2} of the `blocks` per-block partial sums, on the device, into partials[2 * kMaxPartialBlocks ..]: the
+// workspace of a loss pass is 2 * kMaxPartialBlocks + 2 doubles
+void launch_partials_reduce(double *partials, int blocks, hipStream_t stream);
 int error_metrics_blocks(int n);
 void launch_error_metrics(const float *errors, int n, double *partials, int blocks, hipStream_t stream);
 void launch_sample_pairs_build(const int *indices, const float *data, size_t nnz, uint2 *pairs, hipStream_t stream);
