@@ -13,13 +13,18 @@
 // deltas every -s iterations, default one epoch), rank 0 prints the lines and writes the five files.
 #include <getopt.h>
 #include <hip/hip_runtime_api.h>
+#include <signal.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cu2rec.hpp"
@@ -60,6 +65,15 @@ void read_all(int fd, void *buf, size_t n) {
 int run_rank(int rank, int nranks, int mode, int sync_every, int merge, const std::string &config_path,
              const std::string &train_path, const std::string &test_path, const std::vector<int> &to_child,
              const std::vector<int> &from_child, int up, int down) {
+    // fault injection for the failure-propagation test (tests/test_host_abi.py), before anything touches a GPU:
+    // CU2REC_TEST_RANK_EXIT="r:code" makes rank r end with that exit code, CU2REC_TEST_RANK_HANG="r" makes rank r sit still
+    // the way a rank inside a collective whose peer died would
+    if (const char *env = std::getenv("CU2REC_TEST_RANK_EXIT")) {
+        int r = -1, code = 0;
+        if (std::sscanf(env, "%d:%d", &r, &code) == 2 && r == rank) _exit(code);
+    }
+    if (const char *env = std::getenv("CU2REC_TEST_RANK_HANG"))
+        if (std::atoi(env) == rank) std::this_thread::sleep_for(std::chrono::seconds(120));
     if (cu2rec_device_count() < nranks) throw std::runtime_error("fewer HIP devices than ranks (-g)");
     cu2rec::check(cu2rec_set_device(rank));
     if (rank == 0) {
@@ -156,16 +170,22 @@ int run_rank(int rank, int nranks, int mode, int sync_every, int merge, const st
 
 // bin/mf -g N: forks the other ranks BEFORE any HIP call (a process that has initialised the GPU must not fork into
 // another GPU user), wires the pipes, runs rank 0 here and collects the children's exit codes.
+// A rank that fails must not leave the others sitting in a collective: every child dies with its parent (PR_SET_PDEATHSIG),
+// and while rank 0 trains a watcher thread reaps the children -- the first one that ends abnormally makes the program kill
+// the rest and exit non-zero at once (fresh exits only: nothing here re-executes a process that has touched a GPU).
 int run_multi_gpu(int nranks, int mode, int sync_every, int merge, const std::string &config_path, const std::string &train_path,
                   const std::string &test_path) {
     std::vector<int> to_child(nranks, -1), from_child(nranks, -1);
     std::vector<pid_t> pids(nranks, 0);
+    const pid_t parent = getpid();
     for (int r = 1; r < nranks; ++r) {
         int down[2], up[2];
         if (pipe(down) != 0 || pipe(up) != 0) return 2;
         const pid_t pid = fork();
         if (pid < 0) return 2;
         if (pid == 0) {
+            prctl(PR_SET_PDEATHSIG, SIGKILL);
+            if (getppid() != parent) _exit(2);  // the parent was gone before the request took effect
             close(down[1]);
             close(up[0]);
             for (int q = 1; q < r; ++q) {
@@ -187,6 +207,35 @@ int run_multi_gpu(int nranks, int mode, int sync_every, int merge, const std::st
         from_child[r] = up[0];
         pids[r] = pid;
     }
+    std::vector<std::atomic<int>> reaped(nranks);  // 0: running, 1: ended cleanly
+    for (auto &v : reaped) v.store(0);
+    std::atomic<bool> finished{false};
+    auto kill_children = [&] {
+        for (int r = 1; r < nranks; ++r)
+            if (!reaped[r].load()) kill(pids[r], SIGKILL);
+    };
+    std::thread watcher([&] {
+        while (!finished.load()) {
+            for (int r = 1; r < nranks; ++r) {
+                if (reaped[r].load()) continue;
+                int status = 0;
+                const pid_t got = waitpid(pids[r], &status, WNOHANG);
+                if (got != pids[r]) continue;
+                if (WIFEXITED(status) && WEXITSTATUS(status) == 0) {
+                    reaped[r].store(1);
+                    continue;
+                }
+                std::cerr << "mf: rank " << r << " ended abnormally (" << (WIFSIGNALED(status) ? "signal " : "exit code ")
+                          << (WIFSIGNALED(status) ? WTERMSIG(status) : WEXITSTATUS(status)) << "); stopping the other ranks\n";
+                reaped[r].store(1);
+                kill_children();
+                for (int q = 1; q < nranks; ++q)
+                    if (!reaped[q].load()) (void)waitpid(pids[q], &status, 0);  // SIGKILL: at once
+                _exit(3);  // rank 0 (this process) may be inside a collective that will never complete
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    });
     int rc = 0;
     try {
         rc = run_rank(0, nranks, mode, sync_every, merge, config_path, train_path, test_path, to_child, from_child, -1, -1);
@@ -194,9 +243,13 @@ int run_multi_gpu(int nranks, int mode, int sync_every, int merge, const std::st
         std::cerr << "mf: " << e.what() << "\n";
         rc = 2;
     }
+    finished.store(true);
+    watcher.join();
+    if (rc != 0) kill_children();  // rank 0 failed: the others may be waiting for it in a collective
     for (int r = 1; r < nranks; ++r) {
         close(to_child[r]);
         close(from_child[r]);
+        if (reaped[r].load()) continue;
         int status = 0;
         if (waitpid(pids[r], &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) rc = rc ? rc : 2;
     }

@@ -9,13 +9,16 @@
 #include "sharded.hpp"
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "kernels.hpp"
 #include "resident.hpp"
@@ -25,16 +28,20 @@ namespace cu2rec {
 
 namespace {
 
-// the few RCCL entry points used (rccl/rccl.h: ncclGetUniqueId, ncclCommInitRank, ncclAllReduce, ncclCommDestroy)
+// The RCCL entry points used.  TYPES and ENUM VALUES come from <rccl/rccl.h> at compile time (ncclUniqueId, ncclComm_t,
+// ncclSum, ncclFloat32 / 64, ncclResult_t); the SYMBOLS are resolved at run time (dlopen: a copy PyTorch has already loaded
+// is reused, otherwise /opt/rocm's), so the single-GPU library does not link RCCL.  The library found at run time must be
+// of the header's major version (ncclGetVersion): the ABI of the calls below is what the header declares.
 struct Rccl {
-    struct UniqueId {
-        char internal[128];
-    };
-    int (*GetUniqueId)(UniqueId *) = nullptr;
-    int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;                  // optional
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    int version = 0;
     bool ok = false;
     std::string why;
 };
@@ -57,44 +64,118 @@ Rccl &rccl() {
             r.why = std::string("cannot load librccl: ") + dlerror();
             return;
         }
-        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
-        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
-        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
-        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-        r.ok = r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy;
-        if (!r.ok) r.why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+        auto sym = [&](const char *name) { return dlsym(h, name); };
+        r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
+        r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!(r.GetVersion && r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy)) {
+            r.why = "librccl lacks ncclGetVersion / ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+            return;
+        }
+        if (r.GetVersion(&r.version) != ncclSuccess) {
+            r.why = "ncclGetVersion failed";
+            return;
+        }
+        // NCCL_VERSION_CODE = major * 10000 + minor * 100 + patch since 2.9 (rccl.h); the calls used here have been stable
+        // across the 2.x line, another major version is not trusted
+        const int major = r.version >= 10000 ? r.version / 10000 : r.version / 1000;
+        if (major != NCCL_MAJOR) {
+            r.why = "librccl reports version " + std::to_string(r.version) + ", the library was built against " +
+                    std::to_string(NCCL_VERSION_CODE) + " (rccl/rccl.h): another major version";
+            return;
+        }
+        r.ok = true;
     });
     if (!r.ok) fail(CU2REC_EUNSUPPORTED, "cu2rec_amd: RCCL is not available (" + r.why + ")");
     return r;
 }
 
-void rccl_check(int code, const char *what) {
-    if (code == 0) return;
+void rccl_check(ncclResult_t code, const char *what) {
+    if (code == ncclSuccess) return;
     Rccl &r = rccl();
     fail(CU2REC_EHIP, std::string("RCCL error in ") + what + ": " + (r.GetErrorString ? r.GetErrorString(code) : "?"));
 }
 
-constexpr int kNcclSum = 0, kNcclFloat32 = 7, kNcclFloat64 = 8;  // rccl.h: ncclSum, ncclFloat32, ncclFloat64
+double comm_timeout_seconds() {  // how long a rank waits for a collective before it gives the communicator up
+    static const double t = [] {
+        const char *env = std::getenv("CU2REC_COMM_TIMEOUT_S");
+        const double v = env ? std::atof(env) : 600.0;
+        return v > 0 ? v : 600.0;
+    }();
+    return t;
+}
 
 }  // namespace
 
 Comm::~Comm() {
-    if (nccl && owns_nccl) (void)rccl().CommDestroy(nccl);
+    if (nccl && owns_nccl) {
+        Rccl &r = rccl();
+        // a communicator that has seen a failure is aborted, not destroyed: ncclCommDestroy waits for outstanding work
+        if (broken && r.CommAbort) (void)r.CommAbort(static_cast<ncclComm_t>(nccl));
+        else (void)r.CommDestroy(static_cast<ncclComm_t>(nccl));
+    }
+}
+
+// Waits for everything queued on `stream` -- in particular a collective -- without hanging for ever on a peer that died: polls
+// the stream and RCCL's asynchronous error state; on an error or after CU2REC_COMM_TIMEOUT_S (default 600 s) the communicator
+// is aborted (ncclCommAbort: the local kernels are torn down) and the call fails, so that the process can exit non-zero
+// instead of sitting in the collective.
+void Comm::wait(hipStream_t stream) {
+    if (!nccl) {
+        CU2REC_HIP(hipStreamSynchronize(stream));
+        return;
+    }
+    Rccl &r = rccl();
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return;
+        if (q != hipErrorNotReady) CU2REC_HIP(q);
+        std::string why;
+        if (r.CommGetAsyncError) {
+            ncclResult_t async = ncclSuccess;
+            const ncclResult_t rc = r.CommGetAsyncError(static_cast<ncclComm_t>(nccl), &async);
+            if (rc != ncclSuccess) why = std::string("ncclCommGetAsyncError: ") + (r.GetErrorString ? r.GetErrorString(rc) : "?");
+            else if (async != ncclSuccess && async != ncclInProgress)
+                why = std::string("asynchronous RCCL error: ") + (r.GetErrorString ? r.GetErrorString(async) : "?");
+        }
+        if (why.empty() && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_seconds())
+            why = "a collective did not complete within " + std::to_string(static_cast<int>(comm_timeout_seconds())) +
+                  " s (CU2REC_COMM_TIMEOUT_S): did another rank die?";
+        if (!why.empty()) {
+            broken = true;
+            if (r.CommAbort && owns_nccl) {
+                (void)r.CommAbort(static_cast<ncclComm_t>(nccl));
+                nccl = nullptr;
+            }
+            fail(CU2REC_EHIP, "cu2rec_comm (rank " + std::to_string(rank) + " of " + std::to_string(nranks) + "): " + why);
+        }
+        if (++spins < 2000) std::this_thread::yield();  // a collective of this path takes tens of microseconds
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
 }
 
 void Comm::allreduce(void *buf, size_t count, bool is_double, hipStream_t stream) const {
     if (count == 0 || (nranks == 1 && !nccl)) return;  // (a one-rank RCCL communicator exists for tests only)
     if (nccl) {
-        rccl_check(rccl().AllReduce(buf, buf, count, is_double ? kNcclFloat64 : kNcclFloat32, kNcclSum, nccl, stream), "ncclAllReduce");
+        rccl_check(rccl().AllReduce(buf, buf, count, is_double ? ncclFloat64 : ncclFloat32, ncclSum, static_cast<ncclComm_t>(nccl), stream),
+                   "ncclAllReduce");
         return;
     }
     require(fn != nullptr, "cu2rec_comm: no communicator behind a multi-rank job");
     if (fn(ctx, buf, count, is_double ? 1 : 0, stream) != 0) fail(CU2REC_EHIP, "cu2rec_comm: the caller's all-reduce failed");
 }
 
+static_assert(sizeof(ncclUniqueId) == 128, "include/cu2rec_amd.h hands the unique id around as 128 bytes");
+
 void comm_unique_id(void *id_out128) {
-    Rccl::UniqueId id;
+    ncclUniqueId id;
     rccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
     std::memcpy(id_out128, id.internal, sizeof(id.internal));
 }
@@ -108,10 +189,12 @@ Comm *comm_create_rccl(const void *id128, int rank, int nranks) {
     // CU2REC_RCCL_WORLD1=1: a real communicator even for one rank, so that a one-GPU box exercises ncclAllReduce
     const char *force = std::getenv("CU2REC_RCCL_WORLD1");
     if (nranks > 1 || (force && *force == '1')) {
-        Rccl::UniqueId id;
+        ncclUniqueId id;
         std::memcpy(id.internal, id128, sizeof(id.internal));
         try {
-            rccl_check(rccl().CommInitRank(&c->nccl, nranks, id, rank), "ncclCommInitRank");
+            ncclComm_t made = nullptr;
+            rccl_check(rccl().CommInitRank(&made, nranks, id, rank), "ncclCommInitRank");
+            c->nccl = made;
         } catch (...) {
             delete c;
             throw;
@@ -161,6 +244,7 @@ ShardJob::ShardJob(Comm &comm_, DeviceModel &model_, const DeviceCsr &train_, in
     double totals[2] = {static_cast<double>(train.users_with_ratings), static_cast<double>(train.nnz)};
     CU2REC_HIP(hipMemcpy(sums.ptr, totals, sizeof(totals), hipMemcpyHostToDevice));
     comm.allreduce(sums.ptr, 2, true, nullptr);
+    comm.wait(nullptr);
     CU2REC_HIP(hipMemcpy(totals, sums.ptr, sizeof(totals), hipMemcpyDeviceToHost));
     users_total = totals[0];
     nnz_total = totals[1];
@@ -181,7 +265,7 @@ ShardJob::ShardJob(Comm &comm_, DeviceModel &model_, const DeviceCsr &train_, in
         all.upload(rate.data(), rate.size());
         comm.allreduce(all.ptr, rate.size(), true, nullptr);
         std::vector<double> total(rate.size());
-        CU2REC_HIP(hipDeviceSynchronize());
+        comm.wait(nullptr);
         all.download(total.data(), total.size());
         std::vector<float> w(rate.size());
         if (merge == CU2REC_MERGE_WEIGHTED) {
@@ -198,7 +282,7 @@ ShardJob::ShardJob(Comm &comm_, DeviceModel &model_, const DeviceCsr &train_, in
             for (size_t y = 0; y < rate.size(); ++y) phi[y] = -std::expm1(-c * rate[y]);
             all.upload(phi.data(), phi.size());
             comm.allreduce(all.ptr, phi.size(), true, nullptr);
-            CU2REC_HIP(hipDeviceSynchronize());
+            comm.wait(nullptr);
             all.download(phi.data(), phi.size());  // now the sum over the ranks
             for (size_t y = 0; y < rate.size(); ++y) w[y] = static_cast<float>(phi[y] > 0 ? -std::expm1(-c * total[y]) / phi[y] : 1.0);
         }
@@ -251,7 +335,7 @@ void ShardJob::loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq, d
         CU2REC_HIP(hipMemcpyAsync(sums.ptr, host, sizeof(host), hipMemcpyHostToDevice, stream));
         comm.allreduce(sums.ptr, 3, true, stream);
         CU2REC_HIP(hipMemcpyAsync(host, sums.ptr, sizeof(host), hipMemcpyDeviceToHost, stream));
-        CU2REC_HIP(hipStreamSynchronize(stream));
+        comm.wait(stream);  // (bounded: a dead peer ends the call, not the night)
     }
     if (sum_abs) *sum_abs = host[0];
     if (sum_sq) *sum_sq = host[1];

@@ -17,11 +17,15 @@ struct Comm {
     int rank = 0, nranks = 1;
     void *nccl = nullptr;  // ncclComm_t
     bool owns_nccl = false;
+    bool broken = false;   // a collective failed or timed out: the communicator is aborted, not destroyed
     cu2rec_allreduce_fn fn = nullptr;
     void *ctx = nullptr;
     ~Comm();
     // in place, sum over ranks, ordered on `stream` (the callback form may synchronise it)
     void allreduce(void *device_buf, size_t count, bool is_double, hipStream_t stream) const;
+    // hipStreamSynchronize that polls RCCL's asynchronous error state and gives up after CU2REC_COMM_TIMEOUT_S (default 600 s):
+    // aborts the communicator and throws instead of hanging on a peer that died
+    void wait(hipStream_t stream);
 };
 
 void comm_unique_id(void *id_out128);

@@ -191,3 +191,67 @@ def test_bin_mf_g1_flag_and_sharded_cli_single_rank(tmp_path):
         assert res.returncode == 0, res.stderr
         outs.append({c: (d / ("train_f8_%s.csv" % c)).read_text() for c in ("p", "q", "user_bias", "item_bias", "global_bias")})
     assert outs[0] == outs[1]
+
+
+def test_eight_shards_adaptive_merge_within_the_stated_tolerance_of_the_sequential_run():
+    """The acceptance tolerance of a user-sharded run: after 1,000 iterations of the ML-20M shape, f=100, the
+    test RMSE of N = 8 shards -- block-solve mode per shard, item deltas reconciled once per epoch (115 iterations) with the
+    driver's `adaptive` merge, delta = phi(r_total) / sum_k phi(r_k) * sum_k delta_k, phi(r) = 1 - exp(-6 r) -- stays within
+    6e-4 of the unsharded = sequential result (measured in round 2: +3.9e-4; `weighted`: +1.07e-3, pinned here as the bar the
+    adaptive merge must beat).  Eight ranks emulated on ONE GPU: eight engines run one after the other, the merge arithmetic in
+    torch (the driver's own exchange -- wire pack / ncclAllReduce / apply -- is pinned against the oracle by the two-rank test
+    above; this one pins the CONVERGENCE of the merge rule)."""
+    import torch
+    import bench
+    from cu2rec_amd.engine import DeviceRatings, Engine
+    from cu2rec_amd.sharded import plan_users
+    train, test = bench.load_dataset("ml-20m", 20240917, 0, lambda: None)
+    f, iters, sync, n = 100, 1000, 115, 8
+    dev = torch.device("cuda", 0)
+
+    def test_rmse(engines, bounds):
+        ss = 0.0
+        for e, (u0, u1) in zip(engines, bounds):
+            ss += e.loss(DeviceRatings(test.slice_users(u0, u1), dev))["sum_sq"]
+        return (ss / test.nnz) ** 0.5
+
+    base = Engine(train.rows, train.cols, f, train.global_bias, device=dev)
+    base.sgd(DeviceRatings(train, dev), HYPER, 42, 0, iters, "blocksolve")
+    ref = test_rmse([base], [(0, train.rows)])
+    del base
+    P0 = cu.initialize_normal_array(train.rows * f, f).reshape(train.rows, f)
+    ub0 = cu.initialize_normal_array(train.rows, f)
+    b = plan_users(train.rows, n)
+    bounds = list(zip(b[:-1], b[1:]))
+    shards = [train.slice_users(u0, u1) for u0, u1 in bounds]
+    rates = np.stack([cu.api.item_update_rates(s) for s in shards]).astype(np.float64)
+    tot = rates.sum(0)
+    phi = lambda x: -np.expm1(-6.0 * x)
+    alpha = torch.tensor(np.where(tot > 0, phi(tot) / np.maximum(phi(rates).sum(0), 1e-300), 1.0), dtype=torch.float32, device=dev)
+    weights = torch.tensor(np.where(tot > 0, rates / np.maximum(tot, 1e-300), 1.0 / n), dtype=torch.float32, device=dev)
+    got = {}
+    for merge in ("adaptive", "weighted"):
+        engines = [Engine(u1 - u0, train.cols, f, train.global_bias, P=P0[u0:u1], user_bias=ub0[u0:u1], device=dev) for u0, u1 in bounds]
+        d = [DeviceRatings(s, dev) for s in shards]
+        Qb, ibb = engines[0].Q.clone(), engines[0].item_bias.clone()
+        it = 0
+        while it < iters:
+            k = min(sync, iters - it)
+            for e, dr, (u0, _) in zip(engines, d, bounds):
+                e.sgd(dr, HYPER, 42, it, k, "blocksolve", True, u0)
+            it += k
+            dQ = torch.stack([e.Q - Qb for e in engines])[:, :train.cols]
+            dib = torch.stack([e.item_bias - ibb for e in engines])[:, :train.cols]
+            if merge == "adaptive":
+                Qb[:train.cols] += alpha[:, None] * dQ.sum(0)
+                ibb[:train.cols] += alpha * dib.sum(0)
+            else:
+                Qb[:train.cols] += (weights[:, :, None] * dQ).sum(0)
+                ibb[:train.cols] += (weights * dib).sum(0)
+            for e in engines:
+                e.Q.copy_(Qb)
+                e.item_bias.copy_(ibb)
+        got[merge] = test_rmse(engines, bounds) - ref
+        del engines, d
+    assert abs(got["adaptive"]) <= 6e-4, got
+    assert abs(got["adaptive"]) < abs(got["weighted"]), got
