@@ -78,6 +78,29 @@ __global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__rest
     }
 }
 
+// first position in keys[0, n) whose key is >= target
+__device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys, int n, uint32_t target) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Where the chains of the n_ranks most popular items begin in every iteration of a sorted batch: ranges[b][r] = first sorted
+// position of iteration b whose popularity rank is >= r (r = 0 .. n_ranks).  Runs behind the sort on the schedule stream, so
+// that a two-wave block finds its chains with two loads instead of two binary searches of ~17 dependent loads each at the
+// head of every iteration (6-10 us of its ~50: the searches were the first thing the iteration's longest chains did).
+__global__ __launch_bounds__(kBlock) void chain_ranges_kernel(const uint32_t *__restrict__ keys, int n_active, int n_ranks, int item_bits,
+                                                              int *__restrict__ ranges) {
+    const int b = blockIdx.x;
+    const uint32_t *kb = keys + static_cast<size_t>(b) * n_active;
+    const uint32_t key_base = static_cast<uint32_t>(b) << item_bits;
+    for (int r = threadIdx.x; r <= n_ranks; r += kBlock)
+        ranges[static_cast<size_t>(b) * (n_ranks + 1) + r] = lower_bound_key(kb, n_active, key_base + static_cast<uint32_t>(r));
+}
+
 // ---- one update inside a chain: the user's row comes in, the item row / bias stay in registers -------------
 template <int J>
 __device__ __forceinline__ float chain_step(const SgdArgs &a, Row<J> &p, Row<J> &q, float ub, float &ib, float rating) {
@@ -294,22 +317,13 @@ __device__ __forceinline__ void duo_compute(DuoLds<W, S> &l, int buf, int n_vali
     }
 }
 
-// first position in keys[0, n) whose key is >= target
-__device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys, int n, uint32_t target) {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (keys[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
 // One hot block: up to 64 / W chains; wave 0 computes (W lanes per chain), waves 1 and 2 each move half of every
 // tile's memory traffic, wave 3 only keeps the barriers company.
 template <int W, int S>
 __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32_t *__restrict__ keys,
                                                   const uint64_t *__restrict__ vals, int n_active, uint32_t key_base,
-                                                  int n_hot, const int *__restrict__ item_of_rank, int rank_lo) {
+                                                  int n_hot, const int *__restrict__ item_of_rank, int rank_lo,
+                                                  const int *__restrict__ ranges) {
     constexpr int kChains = DuoShape<W, S>::kChains, kTile = DuoShape<W, S>::kTile;
     __shared__ DuoLds<W, S> lds[kChains];
     __shared__ int s_range[kChains][2];
@@ -323,8 +337,13 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
     if (role_a && has_chain) {
         int begin = 0, end = 0;
         if (r < n_hot) {
-            begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
-            end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));
+            if (ranges) {  // chain_ranges_kernel has looked them up behind the sort
+                begin = ranges[r];
+                end = ranges[r + 1];
+            } else {
+                begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
+                end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));
+            }
         }
         if (lane == 0) {
             s_range[c][0] = begin;
@@ -491,10 +510,11 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
                                                              const uint64_t *__restrict__ vals, int n_active,
                                                              const int *__restrict__ item_of_rank,
                                                              uint32_t item_mask, uint32_t key_base, int n_hot,
-                                                             int hot_blocks, int rank_lo) {
+                                                             int hot_blocks, int rank_lo, const int *__restrict__ ranges) {
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
         // two-wave form for every row width: 32 lanes x 1 slot when 65 <= ld <= 128, else 16 lanes x J slots
-        run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank, rank_lo);
+        run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank, rank_lo,
+                                                                         ranges);
         return;
     }
     walk_group<J>(a, keys, vals, n_active, item_of_rank, item_mask, n_hot,
@@ -516,7 +536,7 @@ constexpr int kRoleDuo = 1, kRoleWalk = 2;
 
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
-                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles) {
+                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles, const int *ranges) {
     const int chains_per_block = DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains;
     const int hot_blocks = (std::max(n_hot - rank_lo, 0) + chains_per_block - 1) / chains_per_block;
     const int walk_blocks = (n_active + kGroupsPerBlock - 1) / kGroupsPerBlock;
@@ -528,20 +548,21 @@ void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, 
     const int blocks = hot_blocks + ((roles & kRoleWalk) ? walk_blocks : 0);
     if (blocks == 0) return;
     hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,
-                       item_of_rank, item_mask, key_base, n_hot, hot_blocks, rank_lo);
+                       item_of_rank, item_mask, key_base, n_hot, hot_blocks, rank_lo, ranges);
 }
 
 void launch_chains(const SgdArgs &a, const uint32_t *kb, const uint64_t *vb, int n_active, const int *item_of_rank,
-                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles = kRoleDuo | kRoleWalk) {
+                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles = kRoleDuo | kRoleWalk,
+                   const int *ranges = nullptr) {
     switch (slots_per_lane(a.nslots)) {
-        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
-        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
-        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
-        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
-        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
-        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
-        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
-        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles); break;
+        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
+        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
+        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
+        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
+        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
+        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
+        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
+        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
         default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
     }
 }
@@ -622,7 +643,10 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     while (n_duo_bs < n_cols && n_duo_bs < 4096 && rate[order[n_duo_bs]] >= 12.0) ++n_duo_bs;
     n_duo_bs = std::min(n_duo_bs, (1 << item_bits) - 1);
     max_blocks = n_active / kBsLinks + n_hot_bs + 1;
+    n_range_ranks = std::max(std::max(std::min(n_cols, kHotChains), n_duo_bs), n_hot_bs);
+    n_range_ranks = std::min(n_range_ranks, (1 << item_bits) - 1);
     for (int slot = 0; slot < 2; ++slot) {
+        chain_ranges[slot].allocate(static_cast<size_t>(max_batch) * (n_range_ranks + 1));
         chain_begin[slot].allocate(static_cast<size_t>(max_batch) * (n_hot_bs + 1));
         walk_begin[slot].allocate(max_batch);
         bs_chains[slot].allocate(static_cast<size_t>(max_batch) * std::max(n_hot_bs, 1));
@@ -751,6 +775,9 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(temp.ptr, bytes, dk, dv, static_cast<int>(n), 0,
                                                       item_bits + b_bits + 1, sched));
         ready[slot] = Scheduled{dk.Current(), dv.Current()};
+        hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, ready[slot].sk, n_active, n_range_ranks, item_bits,
+                           chain_ranges[slot].ptr);
+        CU2REC_HIP(hipGetLastError());
         if (blocksolve)
             bs_launch_plan(ready[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
                            bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched);
@@ -857,7 +884,8 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                     CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
                     bs_launch_solve(a, it, stream);
                     launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, static_cast<uint32_t>(b) << item_bits,
-                                  std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs);
+                                  std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, kRoleDuo | kRoleWalk,
+                                  chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1));
                     CU2REC_HIP(hipEventRecord(ev_upd, upd));
                     bs_launch_update(a, it, stream);
                     upd_pending = true;
@@ -878,7 +906,8 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 // phase 1's (measured: 71 instead of 19 us), and a cross-stream edge costs 13-14 us each way on this runtime
                 // (phase 1 -> other chains -> next phase 1 on two streams: 106 us per iteration, 27 of them event latency).
                 launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, static_cast<uint32_t>(b) << item_bits,
-                              std::max(n_duo_bs, n_hot_bs), stream, n_hot_bs);
+                              std::max(n_duo_bs, n_hot_bs), stream, n_hot_bs, kRoleDuo | kRoleWalk,
+                              chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1));
                 // phase 3 on a stream of its own, behind phase 1 (hence behind the previous iteration's other chains, whose rows
                 // it may rewrite, and behind the start of every phase-2 workgroup): its workgroups wait for the chains' progress
                 CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
@@ -903,7 +932,8 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             const uint32_t *kb = sk + static_cast<size_t>(b) * n_active;
             const uint64_t *vb = sv + static_cast<size_t>(b) * n_active;
             const uint32_t key_base = static_cast<uint32_t>(b) << item_bits;
-            launch_chains(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream, 0);
+            launch_chains(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream, 0, kRoleDuo | kRoleWalk,
+                          n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1) : nullptr);
         }
         CU2REC_HIP(hipGetLastError());
         CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));

@@ -57,6 +57,10 @@ struct OrderedSchedule {
     SgdHyper tables_for{};   // hyper-parameters the decay tables were computed from
     bool tables_valid = false;
     DeviceBuffer<int> chain_begin[2], walk_begin[2];
+    // per schedule slot: [iteration of the batch][rank 0 .. n_range_ranks] first sorted position of the chains of the most
+    // popular items (chain_ranges_kernel, behind the sort): the two-wave blocks read their chain's range instead of searching
+    DeviceBuffer<int> chain_ranges[2];
+    int n_range_ranks = 0;
     DeviceBuffer<BsChainDesc> bs_chains[2];
     DeviceBuffer<BsBlockDesc> bs_blocks[2];
     DeviceBuffer<float> tables, Mbuf, ebuf, qstart;
