@@ -25,6 +25,7 @@
 //                              and more, windowed walk for the rest) on a second stream: other items, other users
 // Results equal the sequential ones up to float rounding (not bit for bit: the sums are associated differently).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <mutex>
@@ -1094,12 +1095,15 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
                        item_of_rank, chain_begin, chains, blocks, walk_begin);
 }
 
-void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
+void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
     const size_t gram_lds = static_cast<size_t>(kB) * (a.nslots | 1) * 16 +
                             (static_cast<size_t>(5) * kH * kMS + kGramTabFloats + kB) * 4;
     ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_gram_kernel));
-    hipLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), gram_lds, stream, a, it);
+    // `stop`: an event completed by the kernel's own completion signal (hipExtLaunchKernelGGL) -- a hipEventRecord behind the
+    // launch is a marker packet of its own and held the NEXT launch of the stream back by 6-7 us (kernel traces, round 3)
+    if (stop) hipExtLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), static_cast<uint32_t>(gram_lds), stream, nullptr, stop, 0, a, it);
+    else hipLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), gram_lds, stream, a, it);
     CU2REC_HIP(hipGetLastError());
 }
 

@@ -87,7 +87,7 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
                     hipStream_t stream);
 // the three phases of one iteration's hot chains: three launches that may run at the same time on three streams (phase 2 waits
 // for phase 1's records block by block, phase 3 for phase 2's progress chain by chain, through the words above)
-void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
+void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop = nullptr);
 void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
 void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
 

@@ -26,6 +26,7 @@
 //                        users' rows fetched four links ahead.
 // The arithmetic of one update is the same device code as the Hogwild kernel (sgd_device.hpp).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <hipcub/hipcub.hpp>
 
@@ -536,7 +537,8 @@ constexpr int kRoleDuo = 1, kRoleWalk = 2;
 
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
-                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles, const int *ranges) {
+                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles, const int *ranges,
+                  hipEvent_t stop) {
     const int chains_per_block = DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains;
     const int hot_blocks = (std::max(n_hot - rank_lo, 0) + chains_per_block - 1) / chains_per_block;
     const int walk_blocks = (n_active + kGroupsPerBlock - 1) / kGroupsPerBlock;
@@ -547,22 +549,26 @@ void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, 
     }
     const int blocks = hot_blocks + ((roles & kRoleWalk) ? walk_blocks : 0);
     if (blocks == 0) return;
-    hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,
-                       item_of_rank, item_mask, key_base, n_hot, hot_blocks, rank_lo, ranges);
+    if (stop)  // the event rides on the kernel's completion signal (see bs_launch_gram)
+        hipExtLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, stop, 0, a, keys, vals, n_active,
+                              item_of_rank, item_mask, key_base, n_hot, hot_blocks, rank_lo, ranges);
+    else
+        hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,
+                           item_of_rank, item_mask, key_base, n_hot, hot_blocks, rank_lo, ranges);
 }
 
 void launch_chains(const SgdArgs &a, const uint32_t *kb, const uint64_t *vb, int n_active, const int *item_of_rank,
                    uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles = kRoleDuo | kRoleWalk,
-                   const int *ranges = nullptr) {
+                   const int *ranges = nullptr, hipEvent_t stop = nullptr) {
     switch (slots_per_lane(a.nslots)) {
-        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
-        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
-        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
-        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
-        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
-        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
-        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
-        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges); break;
+        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
+        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
+        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
+        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
+        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
+        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
+        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
+        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
         default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
     }
 }
@@ -876,17 +882,19 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                     if (upd_pending) {  // join: the previous iteration's other chains may have written rows phase 1 reads
                         CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));
                     }
-                    bs_launch_gram(a, it, stream);
                     // The other chains touch other items and other users than the hot ones: fork, run beside, join.  The fork
                     // sits behind phase 1: workgroups of the side kernel that already fill the CUs would keep phase 1's waiting
-                    // (measured: 71 instead of 19 us).
-                    CU2REC_HIP(hipEventRecord(ev_gram, stream));
+                    // (measured: 71 instead of 19 us).  Both events ride on their kernels' completion signals (CU2REC_BS_MARKERS=1:
+                    // separate hipEventRecord markers as in round 2, for comparison).
+                    static const bool markers = std::getenv("CU2REC_BS_MARKERS") != nullptr;
+                    bs_launch_gram(a, it, stream, markers ? nullptr : ev_gram);
+                    if (markers) CU2REC_HIP(hipEventRecord(ev_gram, stream));
                     CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
                     bs_launch_solve(a, it, stream);
                     launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, static_cast<uint32_t>(b) << item_bits,
                                   std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, kRoleDuo | kRoleWalk,
-                                  chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1));
-                    CU2REC_HIP(hipEventRecord(ev_upd, upd));
+                                  chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1), markers ? nullptr : ev_upd);
+                    if (markers) CU2REC_HIP(hipEventRecord(ev_upd, upd));
                     bs_launch_update(a, it, stream);
                     upd_pending = true;
                     continue;
