@@ -446,7 +446,7 @@ def main():
 
     if rank == 0:
         kernels = {"blocksolve": "one block-solve iteration = bs_gram_kernel + bs_solve_kernel + bs_update_kernel, sgd_ordered_kernel beside them "
-                                 "(per-kernel durations: profiles/r02_kernel_stats_blocksolve_*.csv)",
+                                 "(per-kernel durations: profiles/r03_kernel_stats_blocksolve_*.csv)",
                    "hogwild": "sgd_resident_kernel / sgd_hogwild_kernel", "ordered": "sgd_ordered_kernel", "serial": "sgd_serial_kernel"}
         line = {
             "metric": "ratings/sec (SGD updates/sec)", "value": value, "unit": "updates/s", "n_gpus": world,
@@ -463,7 +463,7 @@ def main():
             "timed_region_s_min_max": [round(min(r[0] for r in regions), 6), round(max(r[0] for r in regions), 6)],
             "test_rmse": final["rmse"], "test_rmse_initial": rmse0, "iterations_run": final_iterations,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "traffic_from_profile": "profiles/ (rocprofv3 --pmc passes, fabric-side counters)",
+                         "traffic": None, "traffic_from_profile": "profiles/r03_pmc_blocksolve_ml20m_f100.json (rocprofv3 --pmc passes, fabric-side counters: 225.4 MB per iteration = 1.00x algorithmic on the ML-20M shape)",
                          "kernel": kernels.get(mode, mode), "bytes_per_update": bytes_per_update,
                          "algorithmic_bytes": alg_bytes, "device_seconds": elapsed_dev,
                          "note": "algorithmic bytes of the timed region (rank 0's updates x (16 f + 32)) / its duration by HIP events on "
