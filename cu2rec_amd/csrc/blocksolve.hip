@@ -14,11 +14,13 @@
 //                              block's 64 user rows on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32), scaled into
 //                              lr*L, and its inverse factor M = (I + lr L)^-1 (two 32x32 triangular inversions on the
 //                              vector unit, the off-diagonal tile as two more matrix products) -- so that e = M rhs
-//   phase 2  bs_solve_kernel   one workgroup per hot chain walks its blocks with ONE wavefront, lane = link: a mat-vec
-//                              with the block's rows, a mat-vec with M, a transposed mat-vec -- the only sequential
-//                              part, no cross-wavefront exchange in it; four more wavefronts stream the blocks' rows
-//                              and factors global -> registers -> LDS, four blocks ahead (one CU's load path is what
-//                              bounds a long chain)
+//   phase 2  bs_solve_kernel   one workgroup per hot chain walks its blocks, lane = link, four solver wavefronts splitting
+//                              each step (a mat-vec with the block's rows, a mat-vec with M, a transposed mat-vec) -- the only
+//                              sequential part; four more wavefronts stream the blocks' rows and factors global -> registers
+//                              -> LDS, four blocks ahead.  Opt-in for long chains (cu2rec_blocksolve_affine_blocks): the
+//                              chain's later blocks as ONE affine map each, built by extra workgroups of the same launch
+//                              while the chain's first blocks run, and applied by a second workgroup (see "which chains take
+//                              the affine form")
 //   phase 3  bs_update_kernel  every block in parallel: the item row as each link saw it = a 64x64 (lower triangular) by
 //                              64xf product (matrix cores again), then the user rows and user biases
 //   beside   the other chains  in the ordered mode's own kernel (ordered.hip: two-wave form for chains of a dozen links
@@ -91,6 +93,9 @@ __device__ __forceinline__ void st_agent_u32(unsigned *p, unsigned v) {
 __device__ __forceinline__ void acquire_agent_now() {  // L1 invalidate, complete on return
     asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
 }
+__device__ __forceinline__ void store_through(float *p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v));
+}
 constexpr unsigned long long kSpinTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock: every wait in here is bounded
 
 // v[l] + v[l ^ 16] in every lane
@@ -128,6 +133,7 @@ struct WaveStamp {
     unsigned long long t0;
 #if CU2REC_BS_TRACE
     unsigned long long marks[4] = {0, 0, 0, 0};
+    unsigned long long c0 = clock64();  // shader clock (s_memtime): with the 100 MHz wall clock, the frequency the wavefront ran at
 #endif
     __device__ __forceinline__ explicit WaveStamp(const BsIteration &it) : t0(it.stamps ? wall_clock64() : 0) {}
     __device__ __forceinline__ void mark(const BsIteration &it, int i) {
@@ -151,6 +157,7 @@ struct WaveStamp {
         r[3] = wall_clock64();
 #if CU2REC_BS_TRACE
         for (int i = 0; i < 4; ++i) r[4 + i] = marks[i];
+        if (kernel == 3 || kernel == 4) r[7] = t0 + (clock64() - c0);  // loaders, update: shader cycles in the slot of the last mark
 #endif
     }
 };
@@ -224,6 +231,20 @@ __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict
         off += nb;
     }
     for (int g = s_total + tid; g < max_blocks; g += 256) bd[g] = BsBlockDesc{0, 0, 0, 0};
+}
+
+// ---- which chains take the affine form (long chains, sequential topology) ---------------------------------------------
+// A chain of rank below aff_tails, of at least aff_min_blocks blocks which all lie below aff_cap, is advanced by TWO workgroups
+// of phase 2's launch: its own runs the first aff_head blocks in the plain form and hands the item's state over through memory;
+// meanwhile one more workgroup per block builds the affine maps T' of the other blocks (affine_build_block), and the chain's
+// second workgroup, which has fetched the first of them by then, runs through those at one mat-vec per block.
+__device__ __forceinline__ bool chain_is_affine(const BsIteration &it, int chain) {
+    const BsChainDesc cd = it.chains[chain];
+    const int nblk = (cd.len + kB - 1) / kB;
+    return it.aff_min_blocks > 0 && chain < it.aff_tails && nblk >= it.aff_min_blocks && cd.blk0 + nblk <= it.aff_cap;
+}
+__device__ __forceinline__ bool block_is_affine(const BsIteration &it, const BsBlockDesc &bd) {
+    return it.aff_min_blocks > 0 && bd.m >= it.aff_head && chain_is_affine(it, bd.chain);
 }
 
 // ---- phase 1: the inverse factor of every block --------------------------------------------------------------------
@@ -517,6 +538,378 @@ __device__ __forceinline__ void wait_all_but(int newest) {
     }
 }
 
+// ---- phase 2, beside the chains: the affine maps of the long chains' later blocks ----------------------------------------
+// One workgroup (eight wavefronts) per block.  From phase 1's record (M = (I + lr L)^-1 in three tiles, the base errors) and
+// the block's 64 user rows:
+//     state s = (item row, item bias), user rows extended by a one, Lambda = diag(a, ..., a, c):
+//     e = M (r' - G s0),  G_k = Lambda^k (p_k, 1);   s_end = Lambda^n s0 + lr H^T e,  H_j = Lambda^(n-1-j) (p_j, 1)
+//     =>  s_end = Lambda^n s0 - lr T' (s0, -1),  T' = H^T W,  W = M [G | r'],  e = -W (s0, -1)
+// (tests/test_blocksolve_algebra.py, affine_chain).  W (64 x 128, MFMA, wavefront w < 4: columns 32 w ..) goes to LDS and to
+// memory for phase 3; T' (128 x 128, wavefront v: rows 32 (v >> 1) .., columns 64 (v & 1) ..) goes to memory WRITE-THROUGH:
+// the chain's workgroup -- another CU of this launch -- is waiting for it (flag per block, epoch tagged).  Every LDS read is
+// unconditional and every choice a multiplication by 0 / 1 or a select on registers: an LDS read inside a conditional becomes
+// a branch with a full wait behind it (the first form of this code, a tail of phase 1, took 18 us per block that way).
+__host__ __device__ inline size_t affine_build_lds_bytes(int nslots) {
+    return (static_cast<size_t>(kB) * (nslots | 1) * 4 + 3 * kH * kMS + kB * bs_affine_ws(nslots) + 3 * kB) * 4;
+}
+
+__device__ __forceinline__ void affine_build_block(const SgdArgs &a, const BsIteration &it, int g, float4 *smem, WaveStamp &stamp) {
+    const BsBlockDesc bd = it.blocks[g];
+    if (bd.n_valid == 0 || !block_is_affine(it, bd)) return;  // workgroup uniform
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, k = lane & 31, h = lane >> 5;
+    const int nslots = a.nslots, RS = nslots | 1, RS4 = 4 * RS, F4 = 4 * nslots, TS = bs_affine_ts(nslots), WS = bs_affine_ws(nslots);
+    const int n = bd.n_valid;
+    float4 *tile = smem;                                              // [kB][RS] the user rows, zero past the block's end
+    const float *tilef = reinterpret_cast<const float *>(tile);
+    float *Ms = reinterpret_cast<float *>(smem + kB * RS);            // M11 | M21 | M22, rows of kMS floats
+    float *Ws = Ms + 3 * kH * kMS;                                    // [kB][WS]
+    float *tab = Ws + kB * WS;                                        // a^d | c^d, d in [0, 64)
+    float *basev = tab + 2 * kB;                                      // [kB] r - gb - ub, 0 past the end of a short block
+    {
+        const uint64_t val = it.vals[bd.pos0 + min(lane, n - 1)];
+        const int x = static_cast<int>(val >> 32);
+        // the rows: 8 per wavefront, 8 lanes x 16 bytes per row piece; every load unconditional at a clamped address
+        const int rsub = lane >> 3, cs = lane & 7, row = 8 * wave + rsub;
+        const int xr = __shfl(x, row);
+        const float4 *src = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(xr) * a.ldp);
+        float4 v[4];
+        const float *rec = it.Mbuf + static_cast<size_t>(g) * kBsRecFloats;
+        f32x4 mq[2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = src[min(8 * c + cs, nslots - 1)];
+        // the record: 768 pieces of 16 bytes for the three tiles, 16 for the base errors
+#pragma unroll
+        for (int q = 0; q < 2; ++q) mq[q] = *reinterpret_cast<const f32x4 *>(rec + 4 * min(tid + 512 * q, 3 * 256 + 15));
+        const float ta = it.tables[kTabApow + (tid & 63)], tc = it.tables[kTabCpow + (tid & 63)];
+        for (int c0 = 0; c0 < nslots; c0 += 32) {
+            if (c0 > 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = src[min(c0 + 8 * c + cs, nslots - 1)];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int slot = c0 + 8 * c + cs;
+                if (slot < nslots) tile[row * RS + slot] = row < n ? v[c] : zero4();
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int piece = tid + 512 * q;
+            if (piece < 3 * 256) {
+                const int t = piece >> 8, r = (piece >> 3) & 31, c4 = piece & 7;
+                *reinterpret_cast<f32x4 *>(Ms + (t * kH + r) * kMS + 4 * c4) = mq[q];
+            } else if (piece < 3 * 256 + 16) {
+                *reinterpret_cast<f32x4 *>(basev + 4 * (piece - 3 * 256)) = mq[q];
+            }
+        }
+        if (tid < kB) tab[tid] = ta, tab[kB + tid] = tc;
+    }
+    __syncthreads();
+    stamp.mark(it, 0);
+    if (wave < 4) {
+        const int jc = 32 * wave + k, jcc = min(jc, F4 - 1);
+        const bool is_p = jc < F4, is_c = jc == F4, is_r = jc == F4 + 1;
+        float bl[16], bu[16], m11[16], m21[16], m22[16];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const float4 x11 = *reinterpret_cast<const float4 *>(Ms + k * kMS + 16 * h + 4 * t4);
+            const float4 x21 = *reinterpret_cast<const float4 *>(Ms + (kH + k) * kMS + 16 * h + 4 * t4);
+            const float4 x22 = *reinterpret_cast<const float4 *>(Ms + (2 * kH + k) * kMS + 16 * h + 4 * t4);
+            m11[4 * t4] = x11.x, m11[4 * t4 + 1] = x11.y, m11[4 * t4 + 2] = x11.z, m11[4 * t4 + 3] = x11.w;
+            m22[4 * t4] = x22.x, m22[4 * t4 + 1] = x22.y, m22[4 * t4 + 2] = x22.z, m22[4 * t4 + 3] = x22.w;
+            m21[4 * t4] = x21.x, m21[4 * t4 + 1] = x21.y, m21[4 * t4 + 2] = x21.z, m21[4 * t4 + 3] = x21.w;
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4 += 4) {
+            const float4 al = *reinterpret_cast<const float4 *>(tab + 16 * h + s4), au = *reinterpret_cast<const float4 *>(tab + kH + 16 * h + s4);
+            const float4 cl = *reinterpret_cast<const float4 *>(tab + kB + 16 * h + s4), cu = *reinterpret_cast<const float4 *>(tab + kB + kH + 16 * h + s4);
+            const float4 rl = *reinterpret_cast<const float4 *>(basev + 16 * h + s4), ru = *reinterpret_cast<const float4 *>(basev + kH + 16 * h + s4);
+            const float alv[4] = {al.x, al.y, al.z, al.w}, auv[4] = {au.x, au.y, au.z, au.w};
+            const float clv[4] = {cl.x, cl.y, cl.z, cl.w}, cuv[4] = {cu.x, cu.y, cu.z, cu.w};
+            const float rlv[4] = {rl.x, rl.y, rl.z, rl.w}, ruv[4] = {ru.x, ru.y, ru.z, ru.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kl = 16 * h + s4 + u, ku = kH + kl;
+                float pl = tilef[kl * RS4 + jcc], pu = tilef[ku * RS4 + jcc];
+                asm volatile("" : "+v"(pl), "+v"(pu));  // loaded here, not inside the selects below
+                const float gl = kl < n ? clv[u] : 0.f, gu = ku < n ? cuv[u] : 0.f;
+                bl[s4 + u] = is_p ? pl * alv[u] : is_c ? gl : is_r ? rlv[u] : 0.f;
+                bu[s4 + u] = is_p ? pu * auv[u] : is_c ? gu : is_r ? ruv[u] : 0.f;
+            }
+        }
+        f32x16 wt, wb;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wt[i] = wb[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            wt = __builtin_amdgcn_mfma_f32_32x32x2f32(m11[s], bl[s], wt, 0, 0, 0);
+            wb = __builtin_amdgcn_mfma_f32_32x32x2f32(m21[s], bl[s], wb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wb = __builtin_amdgcn_mfma_f32_32x32x2f32(m22[s], bu[s], wb, 0, 0, 0);
+        if (jc < WS) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {  // (columns past 4 nslots + 1: zeros)
+                const int r0 = acc_row(reg, h), r1 = kH + r0;
+                Ws[r0 * WS + jc] = wt[reg];
+                Ws[r1 * WS + jc] = wb[reg];
+            }
+        }
+    }
+    __syncthreads();
+    stamp.mark(it, 1);
+    // W leaves from LDS as it lies there, 16 bytes per lane (phase 3 reads it: the launch boundary publishes it)
+    float *Wg = it.Wbuf + static_cast<size_t>(g) * bs_affine_w_floats(nslots);
+    for (int idx = tid; idx < kB * (WS >> 2); idx += 512) reinterpret_cast<f32x4 *>(Wg)[idx] = reinterpret_cast<const f32x4 *>(Ws)[idx];
+    // T': this wavefront's 32 rows x 64 columns; eight groups of four contraction steps, the LDS reads of group gq + 1 issued
+    // before the products of group gq (the compiler on its own read every B operand right before its product)
+    {
+        const int wr = wave >> 1, J0 = 2 * (wave & 1);
+        const int i = 32 * wr + k, ic = min(i, F4 - 1);
+        const float fp = i < F4 ? 1.f : 0.f, fc = i == F4 ? 1.f : 0.f;
+        f32x16 acc[2];
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[J][r] = 0.f;
+        float pv[2][4], ta[2][4], tc[2][4], bv[2][2][4];
+        auto read_group = [&](int buf, int gq) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kl = kH * (gq >> 2) + 16 * h + 4 * (gq & 3) + u;
+                const int back = max(n - 1 - kl, 0);
+                pv[buf][u] = tilef[kl * RS4 + ic];
+                ta[buf][u] = tab[back];
+                tc[buf][u] = tab[kB + back];
+#pragma unroll
+                for (int J = 0; J < 2; ++J) bv[buf][J][u] = Ws[kl * WS + 32 * (J0 + J) + k];  // past column WS: the next row, never stored
+            }
+        };
+        auto products = [&](int buf, int gq) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kl = kH * (gq >> 2) + 16 * h + 4 * (gq & 3) + u;
+                // H^T[i][kl] = p_kl[i] a^back (i a column of the row), c^back (i the bias), 0 (past the state)
+                const float av = (pv[buf][u] * ta[buf][u]) * fp + tc[buf][u] * (kl < n ? fc : 0.f);
+#pragma unroll
+                for (int J = 0; J < 2; ++J) acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[buf][J][u], acc[J], 0, 0, 0);
+            }
+        };
+        read_group(0, 0);
+#pragma unroll 1
+        for (int gq = 0; gq < 8; gq += 2) {  // (not unrolled: eight groups' addresses at once cost 70 spilled registers)
+            read_group(1, gq + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            products(0, gq);
+            __builtin_amdgcn_sched_barrier(0);
+            read_group(0, min(gq + 2, 7));
+            __builtin_amdgcn_sched_barrier(0);
+            products(1, gq + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp.mark(it, 2);
+        // whole accumulator tiles (the buffer has room for 128 rows), a row of 32 columns per half wavefront and store
+        float *Tg = it.Tbuf + static_cast<size_t>(g) * bs_affine_t_floats(nslots);
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+            const int col = 32 * (J0 + J) + k;
+            if (col < TS) {
+                float *dst = Tg + static_cast<size_t>(32 * wr + 4 * h) * TS + col;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) store_through(dst + (8 * (reg >> 2) + (reg & 3)) * TS, acc[J][reg]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's part of T' has left the CU ...
+    __syncthreads();                                   // ... and so has everybody else's: the block may be announced
+    if (tid == 0) __hip_atomic_store(it.aff_flag + g, it.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stamp.mark(it, 3);
+    stamp.done(it, 6, g * 8 + wave);
+}
+
+// ---- phase 2, long chains: the affine form ----------------------------------------------------------------------------
+// Phase 1 left T' of every block of the chain (bs_gram_kernel): the block maps the state s = (item row, item bias) to
+// Lambda^n s - lr T' (s, -1).  Two wavefronts apply it (thread i < 128: row i of T' against the state, both read from LDS;
+// the state is double buffered, so ONE barrier per block hands over both the new state and the ring slot), six wavefronts stream
+// the T' blocks (contiguous, (4 nslots + 1) x bs_affine_ts floats, 43.6 KB at f = 100) into a ring of two LDS slots,
+// kDepthA blocks in flight in their registers.  No meeting point inside a block.  The start state of every block goes to
+// phase 3, which recovers the block's errors from it (e = -W (s0, -1)).
+constexpr int kRingA = 2, kDepthA = 4;
+constexpr int kAffApply = 128, kAffLoaders = 512 - kAffApply;
+__host__ __device__ inline int affine_block_f4(int nslots) { return (4 * nslots + 1) * ((nslots + 1) | 1); }
+// the state in LDS: (s, -1, 0 ...) padded with zeros to whole chunks of four 16-byte columns, two chunks past the last one (the
+// apply loop's look-ahead reads them unconditionally: a predicated LDS read becomes a branch with a full wait behind it)
+__host__ __device__ inline int affine_state_f4(int nslots) { return 4 * (((((nslots + 1) | 1) + 3) >> 2) + 2); }
+__host__ __device__ inline size_t affine_lds_bytes(int nslots) {
+    return (static_cast<size_t>(kRingA) * affine_block_f4(nslots) + 2 * affine_state_f4(nslots) + 1) * 16;
+}
+
+// a loader thread's share of block t: float4 numbers lt, lt + kAffLoaders, ... (written as pack expansions: the stages must
+// stay in registers, and a loop the compiler decides not to unroll would put them in scratch memory).  Every load is
+// unconditional at a clamped address, see the loader of the other chains.
+template <int N, int... I>
+__device__ __forceinline__ void aff_issue(f32x4 (&st)[N], const float4 *Tsrc, int t, int nblk, int stride4, int total4, int lt,
+                                          std::integer_sequence<int, I...>) {
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsrc + static_cast<size_t>(min(t, nblk - 1)) * stride4);
+    ((st[I] = src[min(lt + kAffLoaders * I, total4 - 1)]), ...);
+}
+template <int N, int... I>
+__device__ __forceinline__ void aff_commit(const f32x4 (&st)[N], float4 *dst4, int total4, int lt, std::integer_sequence<int, I...>) {
+    f32x4 *dst = reinterpret_cast<f32x4 *>(dst4);
+    ((lt + kAffLoaders * I < total4 ? (void)(dst[lt + kAffLoaders * I] = st[I]) : (void)0), ...);
+}
+
+template <int SW>
+__device__ __forceinline__ void bs_affine_chain(const SgdArgs &a, const BsIteration &it, const BsChainDesc &cd, int chain, float4 *smem,
+                                                WaveStamp &stamp) {
+    constexpr int kNs = 4 * SW < 31 ? 4 * SW : 31;
+    constexpr int NA = ((4 * kNs + 1) * ((kNs + 1) | 1) + kAffLoaders - 1) / kAffLoaders;  // float4 per loader thread and block
+    using Seq = std::make_integer_sequence<int, NA>;
+    const int nslots = a.nslots, F4 = 4 * nslots, R = F4 + 1, n4 = (nslots + 1) | 1;
+    const int total4 = R * n4;
+    const int len = cd.len, nblk = (len + kB - 1) / kB, g0 = cd.blk0;
+    const int n_intervals = (nblk + kDepthA - 1) / kDepthA * kDepthA;
+    const int tid = threadIdx.x;
+    const int stride4 = 128 * n4;  // a block's T' in memory: room for 128 rows
+    const float4 *Tsrc = reinterpret_cast<const float4 *>(it.Tbuf) + static_cast<size_t>(g0) * stride4;
+    // The maps are being built by other workgroups of this launch (affine_build_block) and announced block by block (bounded
+    // waits).  ONE acquire per wavefront, at once: it drops what this CU / XCD still holds of the last iteration's T'; nothing
+    // reads a block's lines again before its flag has been seen.  The loaders need the first five blocks to fill their pipeline;
+    // the appliers look at the flags of ALL blocks (and then wait for the state) before the first barrier, behind which the
+    // loaders ask for the later blocks.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    auto await_map = [&](int m) {  // m < nblk
+        const unsigned long long t0 = wall_clock64();
+        unsigned polls = 0;
+        while (ld_agent(it.aff_flag + g0 + m) != it.epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++polls & 63u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+                __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    };
+    if (tid >= kAffApply) {
+        const int lt = tid - kAffApply;
+        if ((tid & 63) <= kDepthA) await_map(min(tid & 63, nblk - 1));
+        static_assert(kDepthA == 4 && kRingA == 2, "the loop below is written out for four stages and two slots");
+        f32x4 s0[NA], s1[NA], s2[NA], s3[NA];  // four blocks in flight
+        aff_issue(s0, Tsrc, 0, nblk, stride4, total4, lt, Seq{});
+        aff_issue(s1, Tsrc, 1, nblk, stride4, total4, lt, Seq{});
+        aff_issue(s2, Tsrc, 2, nblk, stride4, total4, lt, Seq{});
+        aff_issue(s3, Tsrc, 3, nblk, stride4, total4, lt, Seq{});
+        aff_commit(s0, smem, total4, lt, Seq{});  // block 0
+        aff_issue(s0, Tsrc, 4, nblk, stride4, total4, lt, Seq{});
+        __syncthreads();
+        stamp.mark(it, 0);
+        for (int m0 = 0; m0 < n_intervals; m0 += 4) {  // while block m is applied: block m + 1 into the other slot
+            if (m0 == 8) stamp.mark(it, 1);
+            if (m0 == 16) stamp.mark(it, 2);
+            if (m0 == 24) stamp.mark(it, 3);
+            aff_commit(s1, smem + total4, total4, lt, Seq{});
+            aff_issue(s1, Tsrc, m0 + 5, nblk, stride4, total4, lt, Seq{});
+            __syncthreads();
+            aff_commit(s2, smem, total4, lt, Seq{});
+            aff_issue(s2, Tsrc, m0 + 6, nblk, stride4, total4, lt, Seq{});
+            __syncthreads();
+            aff_commit(s3, smem + total4, total4, lt, Seq{});
+            aff_issue(s3, Tsrc, m0 + 7, nblk, stride4, total4, lt, Seq{});
+            __syncthreads();
+            aff_commit(s0, smem, total4, lt, Seq{});
+            aff_issue(s0, Tsrc, m0 + 8, nblk, stride4, total4, lt, Seq{});
+            __syncthreads();
+        }
+        stamp.done(it, 3, (it.n_hot + chain) * 4 + ((tid >> 6) & 3));
+        return;
+    }
+    __builtin_amdgcn_s_setprio(3);
+    const int i = tid;  // this thread's row of T' = its component of the state
+    const int y = cd.item;
+    const int SB = 4 * affine_state_f4(nslots);                       // floats per state buffer
+    float *sbuf = reinterpret_cast<float *>(smem + kRingA * total4);  // two buffers: (s, -1, 0 ...)
+    const int rc = min(i, R - 1);
+    // The state behind the chain's plain head comes from that workgroup through memory (solve_chain, head_only), one 8-byte
+    // granule {epoch, value} per component: every thread polls its own
+    for (int m = tid; m < nblk; m += kAffApply) await_map(m);
+    float s;
+    {
+        const unsigned long long *gr = it.hstate + static_cast<size_t>(chain) * 128 + min(i, F4);
+        const unsigned long long t0 = wall_clock64();
+        unsigned polls = 0;
+        unsigned long long v;
+        while (static_cast<unsigned>((v = ld_agent(gr)) >> 32) != it.epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++polls & 255u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+                __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        s = i <= F4 ? __uint_as_float(static_cast<unsigned>(v)) : 0.f;  // the item row, then the bias
+    }
+    for (int j = tid; j < 2 * SB; j += kAffApply) {  // both buffers: past the state the constant -1, then zeros
+        const int jj = j < SB ? j : j - SB;
+        if (jj > F4) sbuf[j] = jj == F4 + 1 ? -1.f : 0.f;
+    }
+    if (i < R) sbuf[i] = s;
+    const float lr = a.h.lr;
+    const int n_last = len - kB * (nblk - 1);
+    const float del_full = i < F4 ? it.tables[kTabAdel + kB] : it.tables[kTabCdel + kB];
+    const float del_last = i < F4 ? it.tables[kTabAdel + n_last] : it.tables[kTabCdel + n_last];
+    const int NC = (n4 + 3) >> 2;  // chunks of four 16-byte columns
+    __syncthreads();
+    stamp.mark(it, 0);
+    for (int m = 0; m < n_intervals; ++m) {
+        if (m == 8) stamp.mark(it, 1);
+        if (m == 16) stamp.mark(it, 2);
+        if (m == 24) stamp.mark(it, 3);
+        if (m < nblk) {  // workgroup uniform
+            const float del = m == nblk - 1 ? del_last : del_full;
+            if (i < F4) it.qstart[static_cast<size_t>(g0 + m) * a.ldq + i] = s;
+            if (i == F4) it.bstart[g0 + m] = s;
+            const float4 *row = smem + (m % kRingA) * total4 + rc * n4;
+            const float4 *sb4 = reinterpret_cast<const float4 *>(sbuf + (m & 1) * SB);
+            // packed pairs as they lie in the registers of a 16-byte LDS read: v_pk_fma_f32 without a register move
+            f32x2 acc_lo = {0.f, 0.f}, acc_hi = {0.f, 0.f};
+            f32x4 tv[2][4], sv[2][4];
+            const f32x4 *rowv = reinterpret_cast<const f32x4 *>(row), *sbv = reinterpret_cast<const f32x4 *>(sb4);
+            auto load = [&](int buf, int ch) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = 4 * ch + u;
+                    tv[buf][u] = rowv[min(c, n4 - 1)];
+                    sv[buf][u] = sbv[c];  // zeros past the state
+                }
+            };
+            auto fma4 = [&](int buf) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc_lo = fma2(lo2(tv[buf][u]), lo2(sv[buf][u]), acc_lo);
+                    acc_hi = fma2(hi2(tv[buf][u]), hi2(sv[buf][u]), acc_hi);
+                }
+            };
+            load(0, 0);
+            for (int ch = 0; ch < NC; ch += 2) {
+                load(1, ch + 1);  // past the last chunk: clamped addresses, zero weights
+                __builtin_amdgcn_sched_barrier(0);
+                fma4(0);
+                __builtin_amdgcn_sched_barrier(0);
+                load(0, ch + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                fma4(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const f32x4 acc = {acc_lo[0], acc_lo[1], acc_hi[0], acc_hi[1]};
+            const float t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            s = i < R ? (s - del * s) - lr * t : 0.f;
+            if (i < R) sbuf[((m + 1) & 1) * SB + i] = s;  // the other buffer: nobody reads it in this interval
+        }
+        __syncthreads();
+    }
+    if (i < F4) a.Q[static_cast<size_t>(y) * a.ldq + i] = s;
+    if (i == F4) a.item_bias[y] = s;
+    stamp.done(it, 2, (it.n_hot + chain) * 4 + (tid >> 6));
+}
+
 // Eight wavefronts: four solvers (one per SIMD) and four loaders.
 //   loaders: stream the chain's blocks (64 user rows, the factor tiles, the base errors) into a ring of two LDS slots,
 //            kDepth blocks in flight in their registers; every load unconditional at a clamped address.
@@ -532,8 +925,8 @@ __device__ __forceinline__ void wait_all_but(int newest) {
 // block, write-through stores, announced progress) -- compiled out of the default, sequential instantiation, which is the plain
 // chain: its registers and its loop are not paid for by a mode it does not run (with run-time branches: 256 registers, spills).
 template <int SW, bool CONC>
-__device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration &it, float4 *bs_smem, WaveStamp &stamp, int chain) {
-    const BsChainDesc cd = it.chains[chain];
+__device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration &it, float4 *bs_smem, WaveStamp &stamp, int chain,
+                                            const BsChainDesc &cd, bool head_only = false) {
     const int begin = cd.begin, len = cd.len;
     if (len <= 0) return;  // workgroup uniform
     const int nblk = (len + kB - 1) / kB;
@@ -820,15 +1213,34 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
         solvers_meet(meet, met, k);  // (the loaders have left: the workgroup barrier is not the solvers' alone any more)
         if (tid == 0) st_agent_u64(progress, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(nblk));
     }
-    if (kg == 0) {
-        f32x4 *qdst = reinterpret_cast<f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
+    if (head_only) {
+        // the chain goes on in the affine form in another workgroup (bs_affine_chain): row and bias go there through memory
+        // as 8-byte granules {epoch, value}: the data is the flag (no drain, no second store)
+        unsigned long long *hs = it.hstate + static_cast<size_t>(chain) * 128;
+        const unsigned long long tag = static_cast<unsigned long long>(it.epoch) << 32;
+        if (kg == 0) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int sq = 8 * p + sl, slot = w * SW + sq;
-            if (sq < SW && slot < nslots) qdst[slot] = q4[p];
+            for (int p = 0; p < NP; ++p) {
+                const int sq = 8 * p + sl, slot = w * SW + sq;
+                if (sq < SW && slot < nslots) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        __hip_atomic_store(hs + 4 * slot + c, tag | __float_as_uint(q4[p][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
+        if (tid == 0) __hip_atomic_store(hs + 4 * nslots, tag | __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (kg == 0) {
+            f32x4 *qdst = reinterpret_cast<f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int sq = 8 * p + sl, slot = w * SW + sq;
+                if (sq < SW && slot < nslots) qdst[slot] = q4[p];
+            }
+        }
+        if (tid == 0) a.item_bias[y] = b;
     }
-    if (tid == 0) a.item_bias[y] = b;
     stamp.done(it, 2, chain * 4 + w);
     if (CONC) __syncthreads();  // pairs with the loaders' last barrier
 }
@@ -843,9 +1255,28 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
     WaveStamp stamp(it);
     if (CONC) {
         if (threadIdx.x == 0) __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // "I hold my CU"
-        for (int chain = blockIdx.x; chain < it.n_hot; chain += gridDim.x) solve_chain<SW, true>(a, it, bs_smem, stamp, chain);
+        for (int chain = blockIdx.x; chain < it.n_hot; chain += gridDim.x) solve_chain<SW, true>(a, it, bs_smem, stamp, chain, it.chains[chain]);
     } else if (static_cast<int>(blockIdx.x) < it.n_hot) {
-        solve_chain<SW, false>(a, it, bs_smem, stamp, blockIdx.x);
+        const int chain = blockIdx.x;
+        const BsChainDesc cd = it.chains[chain];
+        // a long chain's head only (see chain_is_affine); the form takes rows of at most 31 slots (bs_affine_supported): compiled
+        // out of the wider instantiations
+        bool head_only = false;
+        if constexpr (SW <= 8) head_only = cd.len > 0 && chain_is_affine(it, chain);  // workgroup uniform
+        solve_chain<SW, false>(a, it, bs_smem, stamp, chain, BsChainDesc{cd.begin, head_only ? it.aff_head * kB : cd.len, cd.blk0, cd.item}, head_only);
+    } else {
+        const int g = static_cast<int>(blockIdx.x) - it.n_hot;
+        if constexpr (SW <= 8) {
+            if (g < it.aff_cap) {
+                affine_build_block(a, it, g, bs_smem, stamp);
+            } else if (g - it.aff_cap < it.aff_tails && chain_is_affine(it, g - it.aff_cap)) {  // workgroup uniform
+                const int chain = g - it.aff_cap;
+                const BsChainDesc cd = it.chains[chain];
+                const int head_links = it.aff_head * kB;
+                bs_affine_chain<SW>(a, it, BsChainDesc{cd.begin + head_links, cd.len - head_links, cd.blk0 + it.aff_head, cd.item}, chain,
+                                    bs_smem, stamp);
+            }
+        }
     }
 }
 
@@ -856,7 +1287,7 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
 // operand and the old value of the update, takes the new values and leaves with eight 16-byte stores per lane; errors,
 // user ids and the powers of a are read from LDS as well (a lane-dependent readlane would turn into branches).
 constexpr int kUpdStride = 36;                               // floats per tile row: 16-byte rows, 2-way conflicts at most
-constexpr int kUpdWaveFloats = kB * kUpdStride + 2 * kB;     // tile | e | user ids
+constexpr int kUpdWaveFloats = kB * kUpdStride + 3 * kB;     // tile | e | user ids | partial errors (affine blocks)
 constexpr int kUpdPowPad = 32;                               // a^d, d in [-32, 64), zero below 0
 __host__ __device__ inline size_t update_lds_bytes(int ntiles) { return (static_cast<size_t>(ntiles) * kUpdWaveFloats + kUpdPowPad + kB) * 4; }
 
@@ -870,6 +1301,7 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
     WaveStamp stamp(it);
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) return;  // workgroup uniform
+    const bool affine = block_is_affine(it, bd);
     for (int i = threadIdx.x; i < kUpdPowPad + kB; i += blockDim.x) pw[i] = i < kUpdPowPad ? 0.f : it.tables[kTabApow + i - kUpdPowPad];
     float *tile = upd_smem + wave * kUpdWaveFloats;
     float *se = tile + kB * kUpdStride;
@@ -904,7 +1336,33 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
     }
     __syncthreads();  // (also: the table of powers)
     const float qs = it.qstart[static_cast<size_t>(g) * a.ldq + colc];
-    const float e_all = it.ebuf[static_cast<size_t>(g) * kB + lane];
+    float e_all;
+    if (affine) {
+        // e = -W (s0, -1): lane = link, this wavefront's share of the 16-byte columns, the shares summed through LDS
+        const int nslots = a.nslots;
+        const float4 *wrow = reinterpret_cast<const float4 *>(it.Wbuf + static_cast<size_t>(g) * bs_affine_w_floats(nslots)) + lane * (nslots + 1);
+        const float4 *q4 = reinterpret_cast<const float4 *>(it.qstart + static_cast<size_t>(g) * a.ldq);
+        const float b0 = it.bstart[g];
+        float part = 0.f;
+        for (int cc = ct; cc <= nslots; cc += ntiles) {
+            const float4 w4 = wrow[cc];
+            const float4 qv = q4[min(cc, nslots - 1)];
+            const float4 sv = cc < nslots ? qv : make_float4(b0, -1.f, 0.f, 0.f);
+            part = __builtin_fmaf(w4.x, sv.x, part);
+            part = __builtin_fmaf(w4.y, sv.y, part);
+            part = __builtin_fmaf(w4.z, sv.z, part);
+            part = __builtin_fmaf(w4.w, sv.w, part);
+        }
+        float *parts = upd_smem + ct * kUpdWaveFloats + kB * kUpdStride + 2 * kB;
+        parts[lane] = part;
+        __syncthreads();
+        float sum = 0.f;
+        for (int w = 0; w < ntiles; ++w) sum += upd_smem[w * kUpdWaveFloats + kB * kUpdStride + 2 * kB + lane];
+        e_all = -sum;
+        if (ct == 0) it.ebuf[static_cast<size_t>(g) * kB + lane] = mine ? e_all : 0.f;  // for the record (tests read the errors back)
+    } else {
+        e_all = it.ebuf[static_cast<size_t>(g) * kB + lane];
+    }
     const float e = mine ? e_all : 0.f;
     se[lane] = e;
     sx[lane] = x;
@@ -986,13 +1444,14 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
 
 template <int SW>
 void launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
-    const size_t lds = solve_lds_bytes(a.nslots, SW);
+    const size_t lds = std::max(solve_lds_bytes(a.nslots, SW),
+                                it.aff_min_blocks > 0 ? std::max(affine_lds_bytes(a.nslots), affine_build_lds_bytes(a.nslots)) : static_cast<size_t>(0));
     if (it.concurrent) {
         ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, true>));
         hipLaunchKernelGGL((bs_solve_kernel<SW, true>), dim3(bs_solve_grid(it.n_hot)), dim3(512), lds, stream, a, it);
     } else {
         ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, false>));
-        hipLaunchKernelGGL((bs_solve_kernel<SW, false>), dim3(it.n_hot), dim3(512), lds, stream, a, it);
+        hipLaunchKernelGGL((bs_solve_kernel<SW, false>), dim3(it.n_hot + (it.aff_min_blocks > 0 ? it.aff_cap + it.aff_tails : 0)), dim3(512), lds, stream, a, it);
     }
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
@@ -1073,7 +1532,7 @@ void bs_check_fault() {
 
 bool bs_supported(int nslots) { return nslots >= 1 && nslots <= kBsMaxSlots; }
 
-int bs_solve_grid(int n_hot) {
+int bs_compute_units() {
     static std::mutex mutex;
     static std::vector<int> cus;  // per device
     int dev = 0;
@@ -1081,8 +1540,10 @@ int bs_solve_grid(int n_hot) {
     std::lock_guard<std::mutex> lock(mutex);
     if (static_cast<int>(cus.size()) <= dev) cus.resize(dev + 1, 0);
     if (!cus[dev]) CU2REC_HIP(hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev));
-    return std::max(1, std::min(n_hot, cus[dev] / 2));
+    return cus[dev];
 }
+
+int bs_solve_grid(int n_hot) { return std::max(1, std::min(n_hot, bs_compute_units() / 2)); }
 
 void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream) {
     hipLaunchKernelGGL(bs_tables_kernel, dim3(1), dim3(128), 0, stream, h, tables);

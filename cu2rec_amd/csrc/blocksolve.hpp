@@ -48,6 +48,18 @@ struct BsIteration {
     float *ebuf;              // [max_blocks][kBsLinks]      error of each hot link
     float *qstart;            // [max_blocks][ldq]           item row at the start of each block
     int max_blocks;
+    // Long chains (at least aff_min_blocks blocks; 0 = none; sequential topology only): every block's effect on the item state
+    // (row, bias) as ONE affine map built in phase 1, so that phase 2 is one mat-vec per block with no meeting point
+    // (blocksolve.hip, "affine form")
+    int aff_min_blocks;
+    int aff_head;             // blocks a long chain runs in the plain form while the maps of its other blocks are being built
+    int aff_cap;              // blocks [0, aff_cap) may take the form: phase 2's launch has a workgroup for each of them
+    unsigned *aff_flag;       // [max_blocks] epoch of the iteration whose T' / W of the block are in memory
+    int aff_tails;            // chains [0, aff_tails) may take the form: the launch has a second workgroup for each of them
+    unsigned long long *hstate;  // [n_hot][128] the item's row and bias behind the plain head for the chain's second workgroup: {epoch, value}
+    float *Tbuf;              // [max_blocks][bs_affine_t_floats]  T' = H^T W, (4 nslots + 1) rows of bs_affine_ts floats (of 128)
+    float *Wbuf;              // [max_blocks][64][bs_affine_ts]    W = M [G | r']
+    float *bstart;            // [max_blocks]  item bias at the start of each block
     // Hand-over between the three phases, which run as three launches AT THE SAME TIME (ordered.hip): every word carries the
     // iteration's epoch, so nothing is ever reset.
     int concurrent;                   // 1: the phases run as launches side by side and wait for each other through the words
@@ -74,12 +86,22 @@ struct BsIteration {
 void bs_set_stamps(unsigned long long *buf, int cap);
 void bs_get_stamps(unsigned long long **buf, int *cap);
 bool bs_supported(int nslots);
+int bs_compute_units();       // of the current device
 int bs_solve_grid(int n_hot);  // workgroups of phase 2: one per chain, at most half the CUs of the current device
 // bounded device-side waits report through one status word per device: its address, an asynchronous refresh of the host copy
 // behind a call's launches, and the check (throws CU2REC_EHIP once if a wait gave up)
 unsigned *bs_status_word();
 void bs_report_status(hipStream_t stream);
 void bs_check_fault();
+// the affine form needs the state (row, bias) and the constant column inside 128 columns: n_factors <= 124
+__host__ __device__ inline bool bs_affine_supported(int nslots) { return nslots <= 31; }
+// floats per row of T': the columns 4 nslots + 2, in 16-byte pieces, an odd number of them (LDS bank spread)
+__host__ __device__ inline int bs_affine_ts(int nslots) { return 4 * ((nslots + 1) | 1); }
+// (room for 128 rows: phase 1 stores whole accumulator tiles, the rows past 4 nslots + 1 are never read)
+__host__ __device__ inline size_t bs_affine_t_floats(int nslots) { return static_cast<size_t>(128) * bs_affine_ts(nslots); }
+// floats per row of W: the columns 4 nslots + 2, in 16-byte pieces
+__host__ __device__ inline int bs_affine_ws(int nslots) { return 4 * (nslots + 1); }
+__host__ __device__ inline size_t bs_affine_w_floats(int nslots) { return static_cast<size_t>(kBsLinks) * bs_affine_ws(nslots); }
 void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream);
 // one workgroup per iteration of the batch: chain and block descriptors
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,

@@ -693,6 +693,38 @@ OrderedSchedule::~OrderedSchedule() {
 }
 
 namespace {
+std::atomic<int> g_bs_affine_blocks{-1};  // -1: not yet initialised from the environment
+}
+
+int blocksolve_affine_blocks(int blocks) {
+    int prev = g_bs_affine_blocks.load();
+    if (prev < 0) {
+        const char *env = std::getenv("CU2REC_BLOCKSOLVE_AFFINE");
+        const int init = env ? std::max(0, std::atoi(env)) : 0;
+        g_bs_affine_blocks.compare_exchange_strong(prev, init);
+        prev = g_bs_affine_blocks.load();
+    }
+    if (blocks >= 0) g_bs_affine_blocks.store(blocks);
+    return prev;
+}
+
+namespace {
+std::atomic<int> g_bs_affine_head{-1};  // -1: not yet initialised from the environment
+}
+
+int blocksolve_affine_head(int blocks) {
+    int prev = g_bs_affine_head.load();
+    if (prev < 0) {
+        const char *env = std::getenv("CU2REC_BLOCKSOLVE_AFFINE_HEAD");
+        const int init = env ? std::max(1, std::atoi(env)) : 9;
+        g_bs_affine_head.compare_exchange_strong(prev, init);
+        prev = g_bs_affine_head.load();
+    }
+    if (blocks >= 1) g_bs_affine_head.store(blocks);
+    return prev;
+}
+
+namespace {
 // explicit threshold (> 0), or <= 0: automatic (240 per 131,072 rating users, scaled with the set); -2 = not yet initialised
 // from the environment
 std::atomic<float> g_bs_min_rate{-2.f};
@@ -848,6 +880,25 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             const double la = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.q_reg));
             const double lc = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.ib_reg));
             unsigned *status = bs_status_word();
+            // chains of at least this many blocks take the affine form (sequential topology, n_factors <= 124)
+            // ... with their first aff_head blocks in the plain form (what the maps of the others take to build) in one workgroup and
+            // the rest in another (at most aff_tails chains), and only as many blocks as the launch of phase 2 can hold a workgroup
+            // for beside those: every workgroup of that launch must find a CU without another one of them leaving (the chains'
+            // second workgroups wait for the builders and for the first ones)
+            const int aff_head = blocksolve_affine_head(0);
+            const int aff_want = blocksolve_affine_blocks(-1);
+            const int aff_tails = std::min(n_hot_bs, 16);
+            const int aff_cap = std::min(std::max(bs_compute_units() - n_hot_bs - aff_tails, 0), max_blocks);
+            const int aff_min = (!concurrent && aff_want > 0 && bs_affine_supported(a.nslots) && aff_cap > aff_head + 1) ? std::max(aff_want, aff_head + 2) : 0;
+            if (aff_min > 0 && aff_nslots != a.nslots) {
+                CU2REC_HIP(hipStreamSynchronize(stream));
+                Tbuf.allocate(static_cast<size_t>(max_blocks) * bs_affine_t_floats(a.nslots));
+                Wbuf.allocate(static_cast<size_t>(max_blocks) * bs_affine_w_floats(a.nslots));
+                bstart.allocate(max_blocks);
+                hstate.allocate(static_cast<size_t>(std::max(n_hot_bs, 1)) * 128);
+                hstate.zero();  // epochs start at 1
+                aff_nslots = a.nslots;
+            }
             for (int b = 0; b < nb; ++b) {
                 a.iter0 = iter0 + done + b;
                 if (++bs_epoch == 0) ++bs_epoch;
@@ -868,6 +919,15 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.ebuf = ebuf.ptr;
                 it.qstart = qstart.ptr;
                 it.max_blocks = max_blocks;
+                it.aff_min_blocks = aff_min;
+                it.aff_head = aff_head;
+                it.aff_cap = aff_cap;
+                it.aff_flag = gram_flag.ptr;
+                it.aff_tails = aff_tails;
+                it.hstate = hstate.ptr;
+                it.Tbuf = Tbuf.ptr;
+                it.Wbuf = Wbuf.ptr;
+                it.bstart = bstart.ptr;
                 it.concurrent = concurrent ? 1 : 0;
                 it.epoch = bs_epoch;
                 it.gram_flag = gram_flag.ptr;

@@ -64,6 +64,9 @@ struct OrderedSchedule {
     DeviceBuffer<BsChainDesc> bs_chains[2];
     DeviceBuffer<BsBlockDesc> bs_blocks[2];
     DeviceBuffer<float> tables, Mbuf, ebuf, qstart;
+    DeviceBuffer<float> Tbuf, Wbuf, bstart;  // affine form of the long chains' blocks (allocated on first use)
+    DeviceBuffer<unsigned long long> hstate;
+    int aff_nslots = 0;
     // Block-solve mode: an iteration is four launches on three streams that run side by side -- `stream` (the caller's): phase 1,
     // then the other items' chains (two-wave form + walk); `solve`: phase 2; `upd`: phase 3, behind phase 1 (ev_gram).  Phase 2
     // waits for phase 1 block by block and phase 3 for phase 2 chain by chain through device words tagged with the iteration's
@@ -87,5 +90,10 @@ struct OrderedSchedule {
 float blocksolve_min_rate(float rate);
 float blocksolve_min_rate_base();   // the explicit value, or the default the automatic scaling starts from
 bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwise a schedule scales the default with its set
+
+// chains of at least this many blocks of 64 links take the affine form (0: none); blocks < 0 only queries
+int blocksolve_affine_blocks(int blocks);
+// ... after their first `blocks` blocks in the plain form (>= 1; 0 only queries)
+int blocksolve_affine_head(int blocks);
 
 }  // namespace cu2rec

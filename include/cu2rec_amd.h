@@ -281,6 +281,15 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
  * rate > 0 sets an explicit threshold, rate < 0 returns to the automatic one, rate == 0 only queries.  Returns what was in
  * force before the call: the explicit threshold, or -1 for automatic (so passing a returned value back restores it). */
 float cu2rec_blocksolve_min_rate(float rate);
+/* Long chains in the affine form (block-solve mode, n_factors <= 124; wider rows keep the plain form).  A chain of at least
+ * `blocks` blocks of 64 updates (one item, one iteration) runs its first cu2rec_blocksolve_affine_head() blocks as every other
+ * chain does; meanwhile extra workgroups of the same launch build, for each of its other blocks, the matrix that maps the
+ * item's row and bias at the start of the block to those at its end, and the chain runs through those at one matrix-vector
+ * product per block.  Only as many blocks take part as the launch can hold a workgroup for (compute units minus hot chains).
+ * Process-wide, read at every SGD call; 0 = off; CU2REC_BLOCKSOLVE_AFFINE / CU2REC_BLOCKSOLVE_AFFINE_HEAD in the environment
+ * set the initial values.  Both return the previous value; blocks < 0 (head: 0) only queries. */
+int cu2rec_blocksolve_affine_blocks(int blocks);
+int cu2rec_blocksolve_affine_head(int blocks);
 /* Development aid: while `buffer` (device memory, 8 * (1 + 8 * capacity) bytes, zeroed by the caller) is set, every
  * wavefront of the block-solve kernels writes {kernel, id, start, end, 4 marks (trace builds)} in ticks of the 100 MHz device clock into record
  * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 5 walk; records never written stay

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--rate", type=float, default=0.0)
     ap.add_argument("--affine", type=int, default=-1, help="chains of at least this many blocks take the affine form (0: off)")
+    ap.add_argument("--head", type=int, default=0, help="blocks of such a chain in the plain form first")
     ap.add_argument("--skip-small", action="store_true")
     ap.add_argument("--skip-big", action="store_true")
     ap.add_argument("--stamps", action="store_true", help="wavefront timelines of one block-solve iteration")
@@ -31,6 +32,8 @@ def main():
     hyper = (0.01, 0.02, 0.02, 0.02, 0.02)
     if args.affine >= 0:
         api.blocksolve_affine_blocks(args.affine)
+    if args.head > 0:
+        api.blocksolve_affine_head(args.head)
     if not args.skip_small:
         for users, items, nnz, f, iters, rate in ((300, 120, 6000, 10, 5, 2.0), (300, 120, 6000, 100, 70, 2.0),
                                                   (3000, 40, 30000, 100, 6, 1.0), (3000, 40, 30000, 50, 6, 1e9),
@@ -71,12 +74,12 @@ def main():
         rec = rec[rec[:, 0] > 0]
         xcc = rec[:, 0] >> 32
         rec[:, 0] &= 0xffffffff
-        for kid, nm in ((2, "solver"), (6, "warm")):
+        for kid, nm in ((2, "solver"), (6, "build")):
             sel = rec[:, 0] == kid
             print("xcc of", nm, "records (id -> xcc):", [(int(i), int(x)) for i, x in zip(rec[sel, 1][:24], xcc[sel][:24])])
         n = len(rec)
         t_min = rec[:, 2].min()
-        names = {1: "gram", 2: "solver", 3: "loader", 4: "update", 5: "walk", 6: "warm"}
+        names = {1: "gram", 2: "solver", 3: "loader", 4: "update", 5: "walk", 6: "build"}
         print("stamps: %d wavefront records; times in us from the first start" % n)
         for kid in sorted(names):
             r = rec[rec[:, 0] == kid]
@@ -92,8 +95,18 @@ def main():
                 mk = (rr[:, 4:] - rr[:, 2:3]) / 100.0
                 print("   marks after start (mean us over %d waves):" % len(rr), [round(float(v), 2) for v in mk.mean(axis=0)])
                 if kid in (2, 3):
-                    for row in rr[:6]:
+                    for row in list(rr[:4]) + list(rr[-6:]):
                         print("     chain %d wave %d:" % (row[1] // 4, row[1] % 4), [round(float(v - row[2]) / 100.0, 2) for v in row[4:]], "end", round(float(row[3] - row[2]) / 100.0, 2))
+            if kid in (3, 4):
+                cyc = (r[:, 7] - r[:, 2]).astype(np.float64)
+                tick = (r[:, 3] - r[:, 2]).astype(np.float64)
+                ok = tick > 0
+                ghz = cyc[ok] / (tick[ok] * 10.0)
+                print("   shader clock over the wavefront's life: mean %.3f GHz (p10 %.3f, p90 %.3f)" % (ghz.mean(), np.percentile(ghz, 10), np.percentile(ghz, 90)))
+            if kid == 1:
+                order = np.argsort(-en)[:6]
+                for i in order:
+                    print("     last gram waves: id %d start %.2f end %.2f marks" % (r[i, 1], st[i], en[i]), [round(float(v - r[i, 2]) / 100.0, 2) for v in r[i, 4:]])
             if kid == 2:
                 order = np.argsort(-dur)[:8]
                 print("   longest solver waves (chain, start, end):", [(int(r[i, 1]) // 4, round(float(st[i]), 2), round(float(en[i]), 2)) for i in order])
