@@ -193,11 +193,12 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
 __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict__ keys, int n_active, int n_hot,
                                                       int item_bits, int max_blocks, const int *__restrict__ item_of_rank,
                                                       int *__restrict__ chain_begin, BsChainDesc *__restrict__ chains,
-                                                      BsBlockDesc *__restrict__ blocks, int *__restrict__ walk_begin) {
+                                                      BsBlockDesc *__restrict__ blocks, int *__restrict__ walk_begin, size_t stride,
+                                                      int batch_keys) {
     __shared__ int s_part[256];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t *kb = keys + static_cast<size_t>(b) * n_active;
-    const uint32_t key_base = static_cast<uint32_t>(b) << item_bits;
+    const uint32_t *kb = keys + static_cast<size_t>(b) * stride;  // iteration b's share of the sorted keys
+    const uint32_t key_base = batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u;  // (keys with / without the iteration above the rank)
     int *cb = chain_begin + static_cast<size_t>(b) * (n_hot + 1);
     BsChainDesc *cd = chains + static_cast<size_t>(b) * max(n_hot, 1);
     BsBlockDesc *bd = blocks + static_cast<size_t>(b) * max_blocks;
@@ -1551,9 +1552,9 @@ void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream) {
 
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
                     const int *item_of_rank, int *chain_begin, BsChainDesc *chains, BsBlockDesc *blocks, int *walk_begin,
-                    hipStream_t stream) {
+                    hipStream_t stream, size_t stride, bool batch_keys) {
     hipLaunchKernelGGL(bs_plan_kernel, dim3(n_batch), dim3(256), 0, stream, keys, n_active, n_hot, item_bits, max_blocks,
-                       item_of_rank, chain_begin, chains, blocks, walk_begin);
+                       item_of_rank, chain_begin, chains, blocks, walk_begin, stride, batch_keys ? 1 : 0);
 }
 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop) {

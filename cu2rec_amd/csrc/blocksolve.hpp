@@ -106,7 +106,7 @@ void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream);
 // one workgroup per iteration of the batch: chain and block descriptors
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
                     const int *item_of_rank, int *chain_begin, BsChainDesc *chains, BsBlockDesc *blocks, int *walk_begin,
-                    hipStream_t stream);
+                    hipStream_t stream, size_t stride, bool batch_keys);
 // the three phases of one iteration's hot chains: three launches that may run at the same time on three streams (phase 2 waits
 // for phase 1's records block by block, phase 3 for phase 2's progress chain by chain, through the words above)
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop = nullptr);

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__rest
                                                                const int *__restrict__ item_rank, int n_rows,
                                                                int n_batch, int item_bits, uint32_t sentinel,
                                                                uint64_t seed, uint64_t iter0, int user_offset,
-                                                               uint32_t *__restrict__ keys, uint64_t *__restrict__ vals) {
+                                                               uint32_t *__restrict__ keys, uint64_t *__restrict__ vals, int batch_keys) {
     const size_t total = static_cast<size_t>(n_rows) * n_batch;
     for (size_t idx = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; idx < total;
          idx += static_cast<size_t>(gridDim.x) * kBlock) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__rest
         if (low != high) {
             const int y_i = sampler_index(seed, static_cast<uint64_t>(user_offset + x), iter0 + b, low, high);
             const int y = indices[y_i];
-            key = (static_cast<uint32_t>(b) << item_bits) | static_cast<uint32_t>(item_rank[y]);
+            key = (batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u) | static_cast<uint32_t>(item_rank[y]);
             val = (static_cast<uint64_t>(static_cast<uint32_t>(x)) << 32) | __float_as_uint(data[y_i]);
         }
         keys[idx] = key;
@@ -89,15 +89,88 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
     return lo;
 }
 
+// The same keys and values, 64 users x up to 64 iterations per workgroup, with the users' RATING ROWS read once instead of one
+// random access per sample: schedule_keys_kernel pulls two cache lines (indices, data) out of memory for every (user, iteration)
+// -- 2.0 GB per batch of 64 iterations on the ML-20M shape, a seventh of what the 64 iterations themselves move, and the
+// iterations running beside it pay for that share of the memory system (tools/schedule_interference.py).  Here a wavefront
+// takes 16 users one after the other: lane b draws iteration b's sample, the row comes in with coalesced loads (256 ratings
+// per round: most users' whole row), the lanes pick their ratings out of the registers (ds_bpermute); rows of more than
+// kRowRounds rounds fall back to two gathers per sample.  The tile leaves through LDS, so that every store is a run of 64
+// consecutive users of one iteration.
+constexpr int kRowRounds = 8;       // x 256 ratings: rows up to 2,048 ratings are read whole
+constexpr int kTileStride = 65;     // LDS words per iteration of the tile (64 users + 1: lanes write columns)
+
+__global__ __launch_bounds__(256) void schedule_keys_tile_kernel(const int *__restrict__ indptr, const int *__restrict__ indices,
+                                                                 const float *__restrict__ data, const int *__restrict__ item_rank,
+                                                                 int n_rows, int n_batch, int item_bits, uint32_t sentinel, uint64_t seed,
+                                                                 uint64_t iter0, int user_offset, uint32_t *__restrict__ keys,
+                                                                 uint64_t *__restrict__ vals, int batch_keys) {
+    __shared__ uint32_t t_key[64 * kTileStride];
+    __shared__ uint32_t t_rat[64 * kTileStride];  // the rating's bits; the user (the value's upper half) is known at the store
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x0 = static_cast<int>(blockIdx.x) * 64;
+    const int b = lane;  // this lane's iteration
+    // the 16 users' row bounds: lane l < 17 holds indptr[x0 + 16 wave + l]
+    const int xi = min(x0 + 16 * wave + min(lane, 16), n_rows);
+    const int bound = indptr[xi];
+    for (int u = 0; u < 16; ++u) {
+        const int x = x0 + 16 * wave + u;
+        if (x >= n_rows) break;  // wavefront uniform
+        const int low = __shfl(bound, u), high = __shfl(bound, u + 1);
+        uint32_t key = sentinel, rat = 0;
+        if (low != high) {  // wavefront uniform
+            const int y_i = b < n_batch ? sampler_index(seed, static_cast<uint64_t>(user_offset + x), iter0 + b, low, high) : low;
+            int y = 0;
+            uint32_t r = 0;
+            if (high - low <= 256 * kRowRounds) {
+                for (int base = low; base < high; base += 256) {
+                    int vi[4];
+                    uint32_t vr[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int e = min(base + 64 * k + lane, high - 1);
+                        vi[k] = indices[e];
+                        vr[k] = __float_as_uint(data[e]);
+                    }
+                    const int pos = y_i - base, src = pos & 63, kk = pos >> 6;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int yi = __shfl(vi[k], src);
+                        const uint32_t ri = __shfl(vr[k], src);
+                        if (kk == k && pos >= 0) y = yi, r = ri;
+                    }
+                }
+            } else {
+                y = indices[y_i];
+                r = __float_as_uint(data[y_i]);
+            }
+            key = (batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u) | static_cast<uint32_t>(item_rank[y]);
+            rat = r;
+        }
+        t_key[b * kTileStride + 16 * wave + u] = key;
+        t_rat[b * kTileStride + 16 * wave + u] = rat;
+    }
+    __syncthreads();
+    const int x = x0 + lane;
+    if (x < n_rows) {
+        for (int bb = wave; bb < n_batch; bb += 4) {
+            const uint32_t key = t_key[bb * kTileStride + lane];
+            const size_t idx = static_cast<size_t>(bb) * n_rows + x;
+            keys[idx] = key;
+            vals[idx] = (key & sentinel) ? 0ull : (static_cast<uint64_t>(static_cast<uint32_t>(x)) << 32) | t_rat[bb * kTileStride + lane];
+        }
+    }
+}
+
 // Where the chains of the n_ranks most popular items begin in every iteration of a sorted batch: ranges[b][r] = first sorted
 // position of iteration b whose popularity rank is >= r (r = 0 .. n_ranks).  Runs behind the sort on the schedule stream, so
 // that a two-wave block finds its chains with two loads instead of two binary searches of ~17 dependent loads each at the
 // head of every iteration (6-10 us of its ~50: the searches were the first thing the iteration's longest chains did).
 __global__ __launch_bounds__(kBlock) void chain_ranges_kernel(const uint32_t *__restrict__ keys, int n_active, int n_ranks, int item_bits,
-                                                              int *__restrict__ ranges) {
+                                                              int *__restrict__ ranges, size_t stride, int batch_keys) {
     const int b = blockIdx.x;
-    const uint32_t *kb = keys + static_cast<size_t>(b) * n_active;
-    const uint32_t key_base = static_cast<uint32_t>(b) << item_bits;
+    const uint32_t *kb = keys + static_cast<size_t>(b) * stride;
+    const uint32_t key_base = batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u;
     for (int r = threadIdx.x; r <= n_ranks; r += kBlock)
         ranges[static_cast<size_t>(b) * (n_ranks + 1) + r] = lower_bound_key(kb, n_active, key_base + static_cast<uint32_t>(r));
 }
@@ -628,6 +701,18 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     hipcub::DoubleBuffer<uint64_t> dv(vals[0][0].ptr, vals[0][1].ptr);
     temp_bytes = 0;
     CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, dk, dv, static_cast<int>(cap), 0, 32, nullptr));
+    {
+        // the segmented form (run()): every iteration of a batch is a segment of n_rows pairs
+        std::vector<int> offs(static_cast<size_t>(max_batch) + 1);
+        for (int b = 0; b <= max_batch; ++b) offs[b] = static_cast<int>(static_cast<size_t>(b) * n_rows);
+        seg_offsets.allocate(offs.size());
+        seg_offsets.upload(offs.data(), offs.size());
+        size_t seg_bytes = 0;
+        CU2REC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, seg_bytes, keys[0][0].ptr, keys[0][1].ptr, vals[0][0].ptr, vals[0][1].ptr,
+                                                               static_cast<int>(cap), max_batch, seg_offsets.ptr, seg_offsets.ptr + 1, 0, 32,
+                                                               nullptr));
+        temp_bytes = std::max(temp_bytes, seg_bytes);
+    }
     temp.allocate(temp_bytes + 16);
     // block-solve workspace
     // the threshold: what the caller set, else scaled with the set -- down (a long chain costs the same whatever the set,
@@ -658,7 +743,16 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         bs_chains[slot].allocate(static_cast<size_t>(max_batch) * std::max(n_hot_bs, 1));
         bs_blocks[slot].allocate(static_cast<size_t>(max_batch) * max_blocks);
     }
-    CU2REC_HIP(hipStreamCreateWithFlags(&sched, hipStreamNonBlocking));
+    {
+        // The next batch's schedule (keys, radix sort, plan: ~0.8 ms of kernels with chip-filling grids per 64 iterations) is built
+        // beside the iterations that consume this batch's: at the LOWEST priority, so that a freed CU goes to an iteration's
+        // workgroup first (the chains' workgroups need most of a CU each and starve behind a sort pass otherwise)
+        static const int sched_prio = std::getenv("CU2REC_SCHED_PRIO") ? std::atoi(std::getenv("CU2REC_SCHED_PRIO")) : 1;  // 0: default priority
+        int lo = 0, hi = 0;
+        CU2REC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (sched_prio) CU2REC_HIP(hipStreamCreateWithPriority(&sched, hipStreamNonBlocking, lo));
+        else CU2REC_HIP(hipStreamCreateWithFlags(&sched, hipStreamNonBlocking));
+    }
     for (int slot = 0; slot < 2; ++slot) {
         CU2REC_HIP(hipEventCreateWithFlags(&ev_ready[slot], hipEventDisableTiming));
         CU2REC_HIP(hipEventCreateWithFlags(&ev_consumed[slot], hipEventDisableTiming));
@@ -797,15 +891,57 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         const uint64_t *sv;
     } ready[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     const int n_batches = (n_iters + max_batch - 1) / max_batch;
+    // SEGMENTED (default): the keys carry the rank only, and every iteration of the batch is sorted as a segment of its own
+    // (hipcub::DeviceSegmentedRadixSort: one workgroup per long segment; stable, so the order is the one the sort of the whole
+    // batch by (iteration, rank) gives).  The whole-batch sort is three chip-filling passes of 130 us each per 64 iterations,
+    // and the iterations that ran beside the schedule kernels took 175 instead of 92 us: a chain's workgroup needs most of a
+    // CU and is not placed while a sort pass keeps refilling every CU (8 us per iteration on average,
+    // tools/schedule_interference.py; stream priorities and more hardware queues change nothing; one slice of small sorts per
+    // iteration is host bound).  CU2REC_SCHED_SEGMENTED=0: the whole-batch sort.
+    static const bool segmented = !(std::getenv("CU2REC_SCHED_SEGMENTED") && std::atoi(std::getenv("CU2REC_SCHED_SEGMENTED")) == 0);
+    static const bool tile_keys = !(std::getenv("CU2REC_SCHED_KEYS_TILE") && std::atoi(std::getenv("CU2REC_SCHED_KEYS_TILE")) == 0);  // max_batch <= 64
+    const size_t seg = segmented ? static_cast<size_t>(n_rows) : static_cast<size_t>(n_active);  // an iteration's stride in the sorted arrays
     auto schedule = [&](int slot, uint64_t first_iter, int nb) {
+        if (segmented) {
+            const size_t n = static_cast<size_t>(nb) * n_rows;
+            const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 1 << 16));
+            if (slot_used[slot]) CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[slot], 0));  // its last batch has been run
+            if (tile_keys)
+                hipLaunchKernelGGL(schedule_keys_tile_kernel, dim3((n_rows + 63) / 64), dim3(256), 0, sched, a.indptr, a.indices, a.data,
+                                   item_rank.ptr, n_rows, nb, item_bits, 1u << item_bits, a.seed, first_iter, a.user_offset, keys[slot][0].ptr,
+                                   vals[slot][0].ptr, 0);
+            else
+                hipLaunchKernelGGL(schedule_keys_kernel, dim3(blocks), dim3(kBlock), 0, sched, a.indptr, a.indices, a.data, item_rank.ptr, n_rows, nb,
+                                   item_bits, 1u << item_bits, a.seed, first_iter, a.user_offset, keys[slot][0].ptr, vals[slot][0].ptr, 0);
+            CU2REC_HIP(hipGetLastError());
+            size_t bytes = temp_bytes;
+            CU2REC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.ptr, bytes, keys[slot][0].ptr, keys[slot][1].ptr, vals[slot][0].ptr,
+                                                                   vals[slot][1].ptr, static_cast<int>(n), nb, seg_offsets.ptr,
+                                                                   seg_offsets.ptr + 1, 0, item_bits + 1, sched));
+            ready[slot] = Scheduled{keys[slot][1].ptr, vals[slot][1].ptr};
+            hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, ready[slot].sk, n_active, n_range_ranks, item_bits,
+                               chain_ranges[slot].ptr, seg, 0);
+            CU2REC_HIP(hipGetLastError());
+            if (blocksolve)
+                bs_launch_plan(ready[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
+                               bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, false);
+            CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
+            slot_used[slot] = true;
+            return;
+        }
         const int b_bits = bits_for(nb);
         const uint32_t sentinel = 1u << (item_bits + b_bits);
         const size_t n = static_cast<size_t>(nb) * n_rows;
         const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 1 << 16));
         if (slot_used[slot]) CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[slot], 0));  // its last batch has been run
-        hipLaunchKernelGGL(schedule_keys_kernel, dim3(blocks), dim3(kBlock), 0, sched, a.indptr, a.indices, a.data,
-                           item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, first_iter, a.user_offset,
-                           keys[slot][0].ptr, vals[slot][0].ptr);
+        if (tile_keys)
+            hipLaunchKernelGGL(schedule_keys_tile_kernel, dim3((n_rows + 63) / 64), dim3(256), 0, sched, a.indptr, a.indices, a.data,
+                               item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, first_iter, a.user_offset, keys[slot][0].ptr,
+                               vals[slot][0].ptr, 1);
+        else
+            hipLaunchKernelGGL(schedule_keys_kernel, dim3(blocks), dim3(kBlock), 0, sched, a.indptr, a.indices, a.data,
+                               item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, first_iter, a.user_offset,
+                               keys[slot][0].ptr, vals[slot][0].ptr, 1);
         CU2REC_HIP(hipGetLastError());
         hipcub::DoubleBuffer<uint32_t> dk(keys[slot][0].ptr, keys[slot][1].ptr);
         hipcub::DoubleBuffer<uint64_t> dv(vals[slot][0].ptr, vals[slot][1].ptr);
@@ -814,11 +950,11 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                                                       item_bits + b_bits + 1, sched));
         ready[slot] = Scheduled{dk.Current(), dv.Current()};
         hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, ready[slot].sk, n_active, n_range_ranks, item_bits,
-                           chain_ranges[slot].ptr);
+                           chain_ranges[slot].ptr, seg, 1);
         CU2REC_HIP(hipGetLastError());
         if (blocksolve)
             bs_launch_plan(ready[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
-                           bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched);
+                           bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, true);
         CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
         slot_used[slot] = true;
     };
@@ -903,8 +1039,8 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 a.iter0 = iter0 + done + b;
                 if (++bs_epoch == 0) ++bs_epoch;
                 BsIteration it{};
-                it.keys = sk + static_cast<size_t>(b) * n_active;
-                it.vals = sv + static_cast<size_t>(b) * n_active;
+                it.keys = sk + static_cast<size_t>(b) * seg;
+                it.vals = sv + static_cast<size_t>(b) * seg;
                 it.n_active = n_active;
                 it.n_hot = n_hot_bs;
                 it.item_mask = item_mask;
@@ -951,7 +1087,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                     if (markers) CU2REC_HIP(hipEventRecord(ev_gram, stream));
                     CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
                     bs_launch_solve(a, it, stream);
-                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, static_cast<uint32_t>(b) << item_bits,
+                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(b) << item_bits,
                                   std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, kRoleDuo | kRoleWalk,
                                   chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1), markers ? nullptr : ev_upd);
                     if (markers) CU2REC_HIP(hipEventRecord(ev_upd, upd));
@@ -973,7 +1109,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 // other users.  On the SAME stream, behind phase 1: beside it their thousands of workgroups take the CUs away from
                 // phase 1's (measured: 71 instead of 19 us), and a cross-stream edge costs 13-14 us each way on this runtime
                 // (phase 1 -> other chains -> next phase 1 on two streams: 106 us per iteration, 27 of them event latency).
-                launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, static_cast<uint32_t>(b) << item_bits,
+                launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(b) << item_bits,
                               std::max(n_duo_bs, n_hot_bs), stream, n_hot_bs, kRoleDuo | kRoleWalk,
                               chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1));
                 // phase 3 on a stream of its own, behind phase 1 (hence behind the previous iteration's other chains, whose rows
@@ -997,9 +1133,9 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         }
         for (int b = 0; b < nb; ++b) {
             a.iter0 = iter0 + done + b;
-            const uint32_t *kb = sk + static_cast<size_t>(b) * n_active;
-            const uint64_t *vb = sv + static_cast<size_t>(b) * n_active;
-            const uint32_t key_base = static_cast<uint32_t>(b) << item_bits;
+            const uint32_t *kb = sk + static_cast<size_t>(b) * seg;
+            const uint64_t *vb = sv + static_cast<size_t>(b) * seg;
+            const uint32_t key_base = segmented ? 0u : static_cast<uint32_t>(b) << item_bits;
             launch_chains(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream, 0, kRoleDuo | kRoleWalk,
                           n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1) : nullptr);
         }

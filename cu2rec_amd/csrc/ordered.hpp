@@ -47,6 +47,7 @@ struct OrderedSchedule {
         const uint64_t *sv = nullptr;
     } spec;
     DeviceBuffer<unsigned char> temp;
+    DeviceBuffer<int> seg_offsets;  // [max_batch + 1] b * n_rows: the iterations of a batch as segments of the sort
     size_t temp_bytes = 0;
     // block-solve mode: items are ranked by their expected updates per iteration (sum over raters of 1 / degree);
     // ranks [0, n_hot_bs) -- at least blocksolve_min_rate() expected updates -- get the block-wise treatment
