@@ -9,12 +9,16 @@
 // is exactly the sequential result.  An iteration becomes a set of independent "item chains".
 //
 // Pipeline for a batch of B iterations (B <= kMaxBatch):
-//   1. schedule_keys_kernel  one thread per (iteration b, user x): draw the rating, emit
-//        key = b << item_bits | popularity_rank(item)        (users without ratings: one bit above all keys)
+//   1. schedule_keys_tile_kernel  for every (iteration b, user x): draw the rating, emit
+//        key = popularity_rank(item)                          (users without ratings: one bit above all ranks)
 //        val = user << 32 | rating bits
-//   2. stable LSB radix sort of the (key, val) pairs (hipCUB/rocPRIM DeviceRadixSort; stability keeps users
-//      ascending inside a chain).  Afterwards iteration b occupies [b * n_active, (b+1) * n_active), chains are
-//      runs of equal keys, and because keys carry the item's popularity RANK, the longest chains come first.
+//      (64 users x 64 iterations per workgroup, a user's rating row read once for all its samples)
+//   2. stable LSB radix sort of the (key, val) pairs, every iteration a segment of its own (hipCUB/rocPRIM
+//      DeviceSegmentedRadixSort; stability keeps users ascending inside a chain).  Afterwards iteration b occupies
+//      [b * n_rows, b * n_rows + n_active), chains are runs of equal keys, and because keys carry the item's popularity
+//      RANK, the longest chains come first.  (The first form -- one thread per sample, keys b << item_bits | rank, ONE sort
+//      of the whole batch, iteration b at [b * n_active, ...) -- is kept behind CU2REC_SCHED_KEYS_TILE=0 /
+//      CU2REC_SCHED_SEGMENTED=0: what it cost the iterations running beside it is in DESIGN.md section 4.)
 //   3. sgd_ordered_kernel, one launch per iteration (the kernel boundary carries the P-row dependency from
 //      iteration b to b+1).  The item row and item bias stay in registers for a whole chain (read and written once
 //      per chain, not once per update).  Two block roles:
