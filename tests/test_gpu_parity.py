@@ -345,6 +345,56 @@ def test_sgd_ordered_bit_exact_vs_oracle(f, iters):
         np.testing.assert_array_equal(g, w, err_msg=name)
 
 
+@pytest.mark.parametrize("segmented,tile", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_sgd_ordered_schedule_forms_give_the_same_result(segmented, tile):
+    """The schedule of a batch can be built in four ways (keys per sample or per rating row x one sort of the whole batch or one
+    segment per iteration: CU2REC_SCHED_SEGMENTED / CU2REC_SCHED_KEYS_TILE, read once per process; both on is the default and what
+    every other test runs).  Each of the four, in a process of its own: the ordered mode -- and the block-solve mode's
+    plan, which is built from the same arrays -- against the oracle on a set with empty users, rows above 2,048 ratings (the
+    row-reading kernel's gather fallback) and 70 iterations (two batches), bit for bit / within 2e-6."""
+    code = r"""
+import numpy as np
+import cu2rec_amd as cu
+from cu2rec_amd import synth
+from oracle import oracle as orc
+tr, _ = synth.make_ratings(700, 3000, 60000, min_degree=3, seed=9)
+indptr = tr.indptr.copy()                       # users 100..139 lose their ratings
+lo, hi = indptr[100], indptr[140]
+indptr[100:141] = lo
+indptr[141:] -= hi - lo
+indices, data = np.delete(tr.indices, np.s_[lo:hi]), np.delete(tr.data, np.s_[lo:hi])
+rng = np.random.RandomState(3)                  # user 7 rates 2,500 items: above the row-reading kernel's 2,048
+l7, h7 = indptr[7], indptr[8]
+big_i = np.arange(2500, dtype=indices.dtype)
+big_r = (rng.randint(1, 11, size=2500) * 0.5).astype(data.dtype)
+indices = np.concatenate([indices[:l7], big_i, indices[h7:]])
+data = np.concatenate([data[:l7], big_r, data[h7:]])
+indptr[8:] += 2500 - (h7 - l7)
+tr = cu.HostCSR(indptr, indices, data, tr.rows, tr.cols, float(data.mean()))
+assert (np.diff(tr.indptr) > 2048).any() and (np.diff(tr.indptr) == 0).any()
+hyper, f, iters = (0.01, 0.02, 0.02, 0.02, 0.02), 20, 70
+o = orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias)
+state = orc.init_model(tr.rows, tr.cols, f)
+orc.sgd_iterations(o, *state, tr.global_bias, hyper, 42, 0, iters, dot_order=orc.DOT_TREE16)
+d = cu.DeviceCSR(tr)
+m = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+m.sgd(d, hyper, 42, 0, iters, mode="ordered")
+for g, w in zip(m.download(), state):
+    assert np.array_equal(g, w)
+cu.api.blocksolve_min_rate(2.0)
+d = cu.DeviceCSR(tr)
+assert d.blocksolve_items() > 0
+m = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+m.sgd(d, hyper, 42, 0, iters, mode="blocksolve")
+assert max(float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(m.download(), state)) <= 2e-6
+print("ok")
+"""
+    env = dict(os.environ, CU2REC_SCHED_SEGMENTED=str(segmented), CU2REC_SCHED_KEYS_TILE=str(tile), PYTHONPATH=ROOT)
+    out = subprocess.run([os.sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600,
+                         cwd=ROOT)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
+
+
 def test_sgd_ordered_resume_empty_users_and_frozen_items():
     m = _toy("toy_missing_user.csv")  # user 2 has no ratings: sentinel keys in the schedule
     f = 10
