@@ -22,7 +22,7 @@ def main():
             if "bs_gram" in name:
                 gram.append(s)
             elif any(k in name for k in ("schedule_keys", "radix_sort", "bs_plan", "chain_ranges", "RadixSort", "onesweep")):
-                sched.append((s, e, name.split("(")[0][-40:]))
+                sched.append((s, e, name))
     gram.sort()
     sched.sort()
     gram = np.array(gram[args.skip:])
@@ -44,6 +44,22 @@ def main():
               % (len(loud), loud.mean(), np.median(loud), busy[busy > 0].mean()))
         print("  excess over the quiet mean: %.1f us per batch of 64 iterations = %.2f us per iteration"
               % ((loud.mean() - quiet.mean()) * len(loud) / max(len(period) / 64.0, 1e-9), (loud.mean() - quiet.mean()) * len(loud) / len(period)))
+    # by kind of schedule kernel: iterations that contain (part of) one of that kind
+    kinds = {"keys": ("schedule_keys",), "sort": ("radix_sort", "RadixSort", "onesweep"), "ranges / plan": ("chain_ranges", "bs_plan")}
+    for kind, pats in kinds.items():
+        mark = np.zeros(len(period), dtype=bool)
+        t_kind = 0.0
+        for s, e, name in sched:
+            if not any(p in name for p in pats) or s < gram[0]:
+                continue
+            t_kind += (e - s) / 1e3
+            i0 = max(np.searchsorted(gram, s, side="right") - 1, 0)
+            i1 = min(np.searchsorted(gram, e, side="right") - 1, len(period) - 1)
+            mark[i0:i1 + 1] = True
+        if mark.any() and len(quiet):
+            print("  %-13s in %5d iterations, mean %.2f us (quiet %.2f): +%.1f us per batch; the kind's GPU time %.1f us per batch"
+                  % (kind, mark.sum(), period[mark].mean(), quiet.mean(), (period[mark].mean() - quiet.mean()) * mark.sum() / (len(period) / 64.0),
+                     t_kind / (len(period) / 64.0)))
     total = sum(e - s for s, e, _ in sched if s >= gram[0]) / 1e3
     print("  schedule kernels: %.1f us of GPU time per iteration" % (total / len(period)))
 
