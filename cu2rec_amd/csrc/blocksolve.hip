@@ -269,6 +269,15 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
     const int g = blockIdx.x;
     WaveStamp stamp(it);
     const BsBlockDesc bd = it.blocks[g];
+    // (every workgroup counts itself through, used or not: the side stream's gate waits for the whole grid)
+    struct Through {
+        unsigned long long *count;
+        __device__ ~Through() {
+            // 32 shards, 128 bytes apart: two thousand atomics on ONE word took longer than phase 1 itself
+            if (count && threadIdx.x == 0)
+                __hip_atomic_fetch_add(count + 16 * (blockIdx.x & 31), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } through_count{it.gram_done};
     if (bd.n_valid == 0) {
         // The last workgroup of the grid (always an unused block: the grid is an upper bound) keeps this launch alive until
         // every chain's workgroup of phase 2 has started: phase 3, queued behind this launch, then finds them on their CUs.
@@ -1258,6 +1267,8 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
         if (threadIdx.x == 0) __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // "I hold my CU"
         for (int chain = blockIdx.x; chain < it.n_hot; chain += gridDim.x) solve_chain<SW, true>(a, it, bs_smem, stamp, chain, it.chains[chain]);
     } else if (static_cast<int>(blockIdx.x) < it.n_hot) {
+        if (it.gram_done && threadIdx.x == 0)  // (the side stream's gate lets the side kernel go once the chains hold their CUs)
+            __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int chain = blockIdx.x;
         const BsChainDesc cd = it.chains[chain];
         // a long chain's head only (see chain_is_affine); the form takes rows of at most 31 slots (bs_affine_supported): compiled
@@ -1566,6 +1577,35 @@ void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream,
     // launch is a marker packet of its own and held the NEXT launch of the stream back by 6-7 us (kernel traces, round 3)
     if (stop) hipExtLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), static_cast<uint32_t>(gram_lds), stream, nullptr, stop, 0, a, it);
     else hipLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), gram_lds, stream, a, it);
+    CU2REC_HIP(hipGetLastError());
+}
+
+namespace {
+__global__ void bs_gate_kernel(const unsigned long long *count, unsigned long long target, const unsigned long long *started,
+                               unsigned long long started_target, unsigned *status) {
+    // lanes 0-31: one shard of phase 1's count each; lane 32: phase 2's workgroups that hold their CU
+    const int lane = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    unsigned polls = 0;
+    for (;;) {
+        unsigned long long v = lane < 32 ? ld_agent(count + 16 * lane) : 0ull;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);  // (lanes 32-63 sum zeros)
+        const unsigned long long sum = __shfl(v, 0);
+        const unsigned long long st = ld_agent(started);
+        if (sum >= target && st >= started_target) break;
+        __builtin_amdgcn_s_sleep(16);
+        if ((++polls & 63u) == 0 && (ld_agent(status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+            if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+}  // namespace
+
+void bs_launch_gate(const unsigned long long *count, unsigned long long target, const unsigned long long *started,
+                    unsigned long long started_target, hipStream_t stream) {
+    hipLaunchKernelGGL(bs_gate_kernel, dim3(1), dim3(64), 0, stream, count, target, started, started_target, bs_status_word());
     CU2REC_HIP(hipGetLastError());
 }
 

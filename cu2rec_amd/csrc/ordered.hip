@@ -772,6 +772,8 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         chain_prog.zero();
         solve_started.allocate(16);
         solve_started.zero();
+        gram_done.allocate(32 * 16);
+        gram_done.zero();
     }
 }
 
@@ -1074,6 +1076,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.chain_prog = chain_prog.ptr;
                 it.status = status;
                 it.solve_started = solve_started.ptr;
+                it.gram_done = nullptr;
                 bs_get_stamps(&it.stamps, &it.stamps_cap);
                 static const int dbg = std::getenv("CU2REC_BS_DBG") ? std::atoi(std::getenv("CU2REC_BS_DBG")) : 0;  // timing experiments
                 it.dbg = dbg;
@@ -1087,10 +1090,24 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                     // (measured: 71 instead of 19 us).  Both events ride on their kernels' completion signals (CU2REC_BS_MARKERS=1:
                     // separate hipEventRecord markers as in round 2, for comparison).
                     static const bool markers = std::getenv("CU2REC_BS_MARKERS") != nullptr;
-                    bs_launch_gram(a, it, stream, markers ? nullptr : ev_gram);
-                    if (markers) CU2REC_HIP(hipEventRecord(ev_gram, stream));
-                    CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
+                    static const bool gate = !(std::getenv("CU2REC_BS_GATE") != nullptr && std::atoi(std::getenv("CU2REC_BS_GATE")) == 0);  // CU2REC_BS_GATE=0: the event
+                    if (gate && !markers && n_hot_bs > 0 && max_blocks > 0) {  // (phase 1 is launched at all)
+                        // The fork without an event: phase 1's workgroups count themselves through, and ONE wavefront queued in front
+                        // of the side kernel (after phase 1 in host order: streams sharing a hardware queue serialise, they cannot
+                        // wait for each other) ends when the whole grid is through.  Phase 1 is a plain launch then: phase 2 starts
+                        // right behind it (an event riding on its completion signal costs 5 us before phase 2).
+                        it.gram_done = gram_done.ptr;
+                        gram_done_target += static_cast<unsigned long long>(max_blocks);
+                        started_total += static_cast<unsigned long long>(n_hot_bs);
+                        bs_launch_gram(a, it, stream);
+                    } else {
+                        bs_launch_gram(a, it, stream, markers ? nullptr : ev_gram);
+                        if (markers) CU2REC_HIP(hipEventRecord(ev_gram, stream));
+                        CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
+                    }
                     bs_launch_solve(a, it, stream);
+                    // (the gate behind phase 2 in host order: it also waits for phase 2's workgroups to hold their CUs)
+                    if (it.gram_done) bs_launch_gate(gram_done.ptr, gram_done_target, solve_started.ptr, started_total, upd);
                     launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(b) << item_bits,
                                   std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, kRoleDuo | kRoleWalk,
                                   chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1), markers ? nullptr : ev_upd);

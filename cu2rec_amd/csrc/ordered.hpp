@@ -73,7 +73,8 @@ struct OrderedSchedule {
     // waits for phase 1 block by block and phase 3 for phase 2 chain by chain through device words tagged with the iteration's
     // epoch (blocksolve.hpp); one event edge per iteration crosses back: phase 3 of iteration i before phase 1 of i + 1 (ev_upd).
     DeviceBuffer<unsigned> gram_flag;
-    DeviceBuffer<unsigned long long> chain_prog, solve_started;
+    DeviceBuffer<unsigned long long> chain_prog, solve_started, gram_done;
+    unsigned long long gram_done_target = 0;  // phase-1 workgroups launched so far (what gram_done will reach)
     unsigned long long started_total = 0;  // phase-2 workgroups launched so far (what solve_started will reach)
     unsigned bs_epoch = 0;
     hipStream_t solve = nullptr, upd = nullptr;
