@@ -73,6 +73,8 @@ struct BsIteration {
     // it starts; the last workgroup of phase 1's grid leaves only when the count has reached this iteration's target --
     // and phase 3 is queued behind phase 1 on the same stream.
     unsigned long long *solve_started;   // [1]  phase-2 workgroups started, over all iterations so far
+    const unsigned long long *side_seq;  // (or null) the word a signal kernel behind the side kernel sets to the iteration's number ...
+    unsigned long long side_target;      // ... and the number phase 3's extra workgroup waits for: the join without an event
     unsigned long long *gram_done;       // [32 x 16]  phase-1 workgroups through (32 shards, 128 bytes apart), over all iterations so far (or null): what the side
                                          //      stream's gate kernel waits for (bs_launch_gate) -- timing only, no data behind it
     unsigned long long started_target;   //      ... including all of this iteration's
@@ -114,6 +116,8 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop = nullptr);
 void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
 // one wavefront that ends once `count` has reached `target` (bounded): queued in front of a kernel that should not start before then
+// one thread that stores `value` to `word` (write-through): queued behind a kernel, it announces that kernel's completion
+void bs_launch_signal(unsigned long long *word, unsigned long long value, hipStream_t stream);
 void bs_launch_gate(const unsigned long long *count, unsigned long long target, const unsigned long long *started,
                     unsigned long long started_target, hipStream_t stream);
 void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream);

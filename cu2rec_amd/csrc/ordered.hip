@@ -774,6 +774,8 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         solve_started.zero();
         gram_done.allocate(32 * 16);
         gram_done.zero();
+        side_seq.allocate(16);
+        side_seq.zero();
     }
 }
 
@@ -1077,14 +1079,18 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.status = status;
                 it.solve_started = solve_started.ptr;
                 it.gram_done = nullptr;
+                it.side_seq = nullptr;
+                it.side_target = 0;
                 bs_get_stamps(&it.stamps, &it.stamps_cap);
                 static const int dbg = std::getenv("CU2REC_BS_DBG") ? std::atoi(std::getenv("CU2REC_BS_DBG")) : 0;  // timing experiments
                 it.dbg = dbg;
                 if (!concurrent) {
                     it.started_target = 0;  // phase 2 is queued behind phase 1: nothing to wait for
-                    if (upd_pending) {  // join: the previous iteration's other chains may have written rows phase 1 reads
+                    static const int gate_mode = std::getenv("CU2REC_BS_GATE") ? std::atoi(std::getenv("CU2REC_BS_GATE")) : 2;
+                    const bool device_join = gate_mode >= 2 && n_hot_bs > 0 && max_blocks > 0 && std::getenv("CU2REC_BS_MARKERS") == nullptr;
+                    if (upd_pending && !device_join) {  // join: the previous iteration's other chains may have written rows phase 1 reads
                         CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));
-                    }
+                    }  // (device_join: the previous iteration's phase 3 has waited for them, see below)
                     // The other chains touch other items and other users than the hot ones: fork, run beside, join.  The fork
                     // sits behind phase 1: workgroups of the side kernel that already fill the CUs would keep phase 1's waiting
                     // (measured: 71 instead of 19 us).  Both events ride on their kernels' completion signals (CU2REC_BS_MARKERS=1:
@@ -1112,6 +1118,13 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                                   std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, kRoleDuo | kRoleWalk,
                                   chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1), markers ? nullptr : ev_upd);
                     if (markers) CU2REC_HIP(hipEventRecord(ev_upd, upd));
+                    if (device_join) {
+                        // a signal kernel behind the side kernel, and one more workgroup in phase 3 that waits for it (queued BEHIND
+                        // the signal in host order): the next phase 1 follows phase 3 without an event
+                        bs_launch_signal(side_seq.ptr, ++side_seq_host, upd);
+                        it.side_seq = side_seq.ptr;
+                        it.side_target = side_seq_host;
+                    }
                     bs_launch_update(a, it, stream);
                     upd_pending = true;
                     continue;

@@ -75,6 +75,8 @@ struct OrderedSchedule {
     DeviceBuffer<unsigned> gram_flag;
     DeviceBuffer<unsigned long long> chain_prog, solve_started, gram_done;
     unsigned long long gram_done_target = 0;  // phase-1 workgroups launched so far (what gram_done will reach)
+    DeviceBuffer<unsigned long long> side_seq;  // [1] number of the last iteration whose side kernel is complete (bs_launch_signal)
+    unsigned long long side_seq_host = 0;
     unsigned long long started_total = 0;  // phase-2 workgroups launched so far (what solve_started will reach)
     unsigned bs_epoch = 0;
     hipStream_t solve = nullptr, upd = nullptr;
