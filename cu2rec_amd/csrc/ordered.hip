@@ -748,14 +748,11 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         bs_blocks[slot].allocate(static_cast<size_t>(max_batch) * max_blocks);
     }
     {
-        // The next batch's schedule (keys, radix sort, plan: ~0.8 ms of kernels with chip-filling grids per 64 iterations) is built
-        // beside the iterations that consume this batch's: at the LOWEST priority, so that a freed CU goes to an iteration's
-        // workgroup first (the chains' workgroups need most of a CU each and starve behind a sort pass otherwise)
-        static const int sched_prio = std::getenv("CU2REC_SCHED_PRIO") ? std::atoi(std::getenv("CU2REC_SCHED_PRIO")) : 1;  // 0: default priority
+        // The next batch's schedule is built beside the iterations that consume this batch's, on a stream of the lowest priority
+        // (measured: no different from the default priority -- what its kernels cost the iterations is DESIGN.md section 4)
         int lo = 0, hi = 0;
         CU2REC_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        if (sched_prio) CU2REC_HIP(hipStreamCreateWithPriority(&sched, hipStreamNonBlocking, lo));
-        else CU2REC_HIP(hipStreamCreateWithFlags(&sched, hipStreamNonBlocking));
+        CU2REC_HIP(hipStreamCreateWithPriority(&sched, hipStreamNonBlocking, lo));
     }
     for (int slot = 0; slot < 2; ++slot) {
         CU2REC_HIP(hipEventCreateWithFlags(&ev_ready[slot], hipEventDisableTiming));
