@@ -33,6 +33,7 @@
 #include <hip/hip_ext.h>
 
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -54,6 +55,19 @@ namespace cu2rec {
 namespace {
 
 using namespace dev;
+
+// The segmented sort of a batch's schedule (one segment per iteration, run()) is rocPRIM's with a block of 1,024 threads instead of
+// its 256: ONE workgroup sorts a segment of n_rows pairs, and with the default block the kernel sat on its 64 CUs for 6.6 ms of
+// every 15 on the Netflix shape (480,189 pairs a segment) -- a quarter of the chip that the throughput-bound phases of that shape
+// then lack (iterations beside it 306 instead of 238 us).  Four times the threads: a quarter of the time.
+#ifndef CU2REC_SEG_BLOCK
+#define CU2REC_SEG_BLOCK 1024
+#endif
+#ifndef CU2REC_SEG_ITEMS
+#define CU2REC_SEG_ITEMS 8
+#endif
+using SegSortConfig = rocprim::segmented_radix_sort_config<8, rocprim::kernel_config<CU2REC_SEG_BLOCK, CU2REC_SEG_ITEMS>,
+                                                           rocprim::WarpSortConfig<8, 4, 256, 64, 16, 8, 256>, true>;
 
 constexpr int kHotChains = 256;  // most popular items: their chains run in the two-wave form (run_hot_block_duo)
 
@@ -117,42 +131,69 @@ __global__ __launch_bounds__(256) void schedule_keys_tile_kernel(const int *__re
     // the 16 users' row bounds: lane l < 17 holds indptr[x0 + 16 wave + l]
     const int xi = min(x0 + 16 * wave + min(lane, 16), n_rows);
     const int bound = indptr[xi];
-    for (int u = 0; u < 16; ++u) {
-        const int x = x0 + 16 * wave + u;
-        if (x >= n_rows) break;  // wavefront uniform
-        const int low = __shfl(bound, u), high = __shfl(bound, u + 1);
-        uint32_t key = sentinel, rat = 0;
-        if (low != high) {  // wavefront uniform
-            const int y_i = b < n_batch ? sampler_index(seed, static_cast<uint64_t>(user_offset + x), iter0 + b, low, high) : low;
-            int y = 0;
-            uint32_t r = 0;
-            if (high - low <= 256 * kRowRounds) {
-                for (int base = low; base < high; base += 256) {
-                    int vi[4];
-                    uint32_t vr[4];
+    // four users at a time: their first 256 ratings (most rows whole) are requested together, the samples drawn while the loads
+    // fly, and their four item ranks looked up together -- a wavefront walking its 16 users one load round trip after the other
+    // kept the kernel (a chip-filling grid beside the iterations) on the CUs 1.6 times as long
+    for (int u0 = 0; u0 < 16; u0 += 4) {
+        int low[4], high[4], y_i[4], y[4], vi[4][4];
+        uint32_t r[4], vr[4][4];
+        bool live[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int e = min(base + 64 * k + lane, high - 1);
-                        vi[k] = indices[e];
-                        vr[k] = __float_as_uint(data[e]);
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + 16 * wave + u0 + j;
+            low[j] = __shfl(bound, u0 + j);
+            high[j] = __shfl(bound, u0 + j + 1);
+            live[j] = x < n_rows && low[j] != high[j];  // wavefront uniform
+            const int last = max(high[j] - 1, low[j]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = live[j] ? min(low[j] + 64 * k + lane, last) : 0;
+                vi[j][k] = indices[e];
+                vr[j][k] = __float_as_uint(data[e]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + 16 * wave + u0 + j;
+            y_i[j] = live[j] && b < n_batch ? sampler_index(seed, static_cast<uint64_t>(user_offset + x), iter0 + b, low[j], high[j]) : low[j];
+            y[j] = 0;
+            r[j] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!live[j]) continue;  // wavefront uniform
+            if (high[j] - low[j] <= 256 * kRowRounds) {
+                for (int base = low[j]; base < high[j]; base += 256) {
+                    if (base > low[j]) {  // (rows above 256 ratings: the further rounds one after the other)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int e = min(base + 64 * k + lane, high[j] - 1);
+                            vi[j][k] = indices[e];
+                            vr[j][k] = __float_as_uint(data[e]);
+                        }
                     }
-                    const int pos = y_i - base, src = pos & 63, kk = pos >> 6;
+                    const int pos = y_i[j] - base, src = pos & 63, kk = pos >> 6;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int yi = __shfl(vi[k], src);
-                        const uint32_t ri = __shfl(vr[k], src);
-                        if (kk == k && pos >= 0) y = yi, r = ri;
+                        const int yi = __shfl(vi[j][k], src);
+                        const uint32_t ri = __shfl(vr[j][k], src);
+                        if (kk == k && pos >= 0) y[j] = yi, r[j] = ri;
                     }
                 }
             } else {
-                y = indices[y_i];
-                r = __float_as_uint(data[y_i]);
+                y[j] = indices[y_i[j]];
+                r[j] = __float_as_uint(data[y_i[j]]);
             }
-            key = (batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u) | static_cast<uint32_t>(item_rank[y]);
-            rat = r;
         }
-        t_key[b * kTileStride + 16 * wave + u] = key;
-        t_rat[b * kTileStride + 16 * wave + u] = rat;
+        int rank[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rank[j] = item_rank[y[j]];  // (item 0 for users without ratings: unused)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t key = live[j] ? (batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u) | static_cast<uint32_t>(rank[j]) : sentinel;
+            t_key[b * kTileStride + 16 * wave + u0 + j] = key;
+            t_rat[b * kTileStride + 16 * wave + u0 + j] = live[j] ? r[j] : 0u;
+        }
     }
     __syncthreads();
     const int x = x0 + lane;
@@ -712,9 +753,9 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         seg_offsets.allocate(offs.size());
         seg_offsets.upload(offs.data(), offs.size());
         size_t seg_bytes = 0;
-        CU2REC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, seg_bytes, keys[0][0].ptr, keys[0][1].ptr, vals[0][0].ptr, vals[0][1].ptr,
-                                                               static_cast<int>(cap), max_batch, seg_offsets.ptr, seg_offsets.ptr + 1, 0, 32,
-                                                               nullptr));
+        CU2REC_HIP(rocprim::segmented_radix_sort_pairs<SegSortConfig>(nullptr, seg_bytes, keys[0][0].ptr, keys[0][1].ptr, vals[0][0].ptr,
+                                                                       vals[0][1].ptr, static_cast<unsigned>(cap), static_cast<unsigned>(max_batch),
+                                                                       seg_offsets.ptr, seg_offsets.ptr + 1, 0u, 32u, nullptr));
         temp_bytes = std::max(temp_bytes, seg_bytes);
     }
     temp.allocate(temp_bytes + 16);
@@ -920,9 +961,10 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                                    item_bits, 1u << item_bits, a.seed, first_iter, a.user_offset, keys[slot][0].ptr, vals[slot][0].ptr, 0);
             CU2REC_HIP(hipGetLastError());
             size_t bytes = temp_bytes;
-            CU2REC_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(temp.ptr, bytes, keys[slot][0].ptr, keys[slot][1].ptr, vals[slot][0].ptr,
-                                                                   vals[slot][1].ptr, static_cast<int>(n), nb, seg_offsets.ptr,
-                                                                   seg_offsets.ptr + 1, 0, item_bits + 1, sched));
+            CU2REC_HIP(rocprim::segmented_radix_sort_pairs<SegSortConfig>(temp.ptr, bytes, keys[slot][0].ptr, keys[slot][1].ptr, vals[slot][0].ptr,
+                                                                           vals[slot][1].ptr, static_cast<unsigned>(n), static_cast<unsigned>(nb),
+                                                                           seg_offsets.ptr, seg_offsets.ptr + 1, 0u,
+                                                                           static_cast<unsigned>(item_bits + 1), sched));
             ready[slot] = Scheduled{keys[slot][1].ptr, vals[slot][1].ptr};
             hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, ready[slot].sk, n_active, n_range_ranks, item_bits,
                                chain_ranges[slot].ptr, seg, 0);
