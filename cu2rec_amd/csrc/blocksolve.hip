@@ -295,10 +295,12 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
         return;
     }
     const int nslots = a.nslots, RS = nslots | 1;
+    // The five 32 x 32 tiles TAKE THE PLACE of the user rows once the Gram products have read them (barrier below): 34.6 instead of
+    // 57.6 KB of LDS at f = 128 -- three workgroups a CU instead of two on the Netflix shape, whose 7,500 blocks come in rounds
     float4 *tile = bs_smem;  // [kB][RS]
-    float *Ms = reinterpret_cast<float *>(bs_smem + gram_tile_float4s(nslots));  // M11 | M22
+    float *Ms = reinterpret_cast<float *>(bs_smem);                               // M11 | M22
     float *Ns = Ms + 2 * kH * kMS;                                                // N00 (later M21) | N11 | N10
-    float *tab = Ms + 5 * kH * kMS;
+    float *tab = Ms + max(static_cast<int>(4 * gram_tile_float4s(nslots)), 5 * kH * kMS);
     float *basev = tab + kGramTabFloats;      // [kB] r - gb - ub, 0 past the end of a short block
     const bool mine = lane < bd.n_valid;  // lane l: link l
     const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
@@ -337,12 +339,12 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
     __syncthreads();
     stamp.mark(it, 1);
     const int k = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     if (wave < 3) {  // 0: G00 -> N00, 1: G11 -> N11, 2: G10 -> N10 (rows: links 32.., columns: links 0..31)
         const int S0 = (nslots + 1) >> 1;  // slots per lane half
         const float4 *ra = tile + (wave == 0 ? k : kH + k) * RS, *rb = tile + (wave == 1 ? kH + k : k) * RS;
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         for (int c = 0; c < S0; c += 2) {
             float4 va[2], vb[2];
 #pragma unroll
@@ -360,6 +362,9 @@ __global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it)
                 for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[e], pb[e], acc, 0, 0, 0);
             }
         }
+    }
+    __syncthreads();  // every wavefront is through with the rows: the tiles take their place
+    if (wave < 3) {
         const float lr = a.h.lr;
         auto entry = [&](int d, float gram) { return lr * (tab[kB + d] + tab[d] * gram); };
 #pragma unroll
@@ -1587,8 +1592,8 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
-    const size_t gram_lds = static_cast<size_t>(kB) * (a.nslots | 1) * 16 +
-                            (static_cast<size_t>(5) * kH * kMS + kGramTabFloats + kB) * 4;
+    const size_t gram_lds = std::max(static_cast<size_t>(kB) * (a.nslots | 1) * 16, static_cast<size_t>(5) * kH * kMS * 4) +
+                            static_cast<size_t>(kGramTabFloats + kB) * 4;
     ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_gram_kernel));
     // `stop`: an event completed by the kernel's own completion signal (hipExtLaunchKernelGGL) -- a hipEventRecord behind the
     // launch is a marker packet of its own and held the NEXT launch of the stream back by 6-7 us (kernel traces, round 3)
