@@ -263,7 +263,7 @@ __device__ __forceinline__ bool block_is_affine(const BsIteration &it, const BsB
 constexpr int kGramTabFloats = 2 * kB;  // a^d | c^d, d in [0, 64)
 __host__ __device__ inline size_t gram_tile_float4s(int nslots) { return static_cast<size_t>(kB) * (nslots | 1); }
 
-__global__ __launch_bounds__(256) void bs_gram_kernel(SgdArgs a, BsIteration it) {
+__global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration it) {
     extern __shared__ float4 bs_smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = blockIdx.x;
