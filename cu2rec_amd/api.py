@@ -400,6 +400,12 @@ def blocksolve_affine_blocks(blocks=-1):
     return lib().cu2rec_blocksolve_affine_blocks(int(blocks))
 
 
+def blocksolve_lookahead_blocks(blocks=-1):
+    """cu2rec_blocksolve_lookahead_blocks: items expected to collect at least this many 64-update blocks per iteration run phase 2
+    in the look-ahead form (0: off, the default; read when a DeviceCSR's schedule is created)."""
+    return lib().cu2rec_blocksolve_lookahead_blocks(int(blocks))
+
+
 def blocksolve_affine_head(blocks=0):
     """cu2rec_blocksolve_affine_head: blocks such a chain runs in the plain form first (>= 1; 0 only queries)."""
     return lib().cu2rec_blocksolve_affine_head(int(blocks))

@@ -144,6 +144,11 @@ struct WaveStamp {
         }
 #endif
     }
+    __device__ __forceinline__ void span(int i, unsigned long long ticks) {  // trace builds: a duration, shown as a mark that far behind the start
+#if CU2REC_BS_TRACE
+        marks[i] = t0 + ticks;
+#endif
+    }
     __device__ __forceinline__ void done(const BsIteration &it, int kernel, int id) const {
         if (!it.stamps || (threadIdx.x & 63) != 0) return;
         const int seg = it.stamps_cap / 8;  // one segment of the buffer per kernel: no atomics, no contention
@@ -166,7 +171,7 @@ struct WaveStamp {
 // every block) cannot bias a hot item's decay rate; the deltas are computed in double from the float hyper-parameters
 __global__ void bs_tables_kernel(SgdHyper h, float *__restrict__ t) {
     const int k = threadIdx.x;
-    if (k > kB) return;
+    if (k > 2 * kB) return;
     const double a = 1.0 - static_cast<double>(h.lr) * static_cast<double>(h.q_reg);
     const double c = 1.0 - static_cast<double>(h.lr) * static_cast<double>(h.ib_reg);
     double ak = 1.0, ck = 1.0;
@@ -248,6 +253,59 @@ __device__ __forceinline__ bool block_is_affine(const BsIteration &it, const BsB
     return it.aff_min_blocks > 0 && bd.m >= it.aff_head && chain_is_affine(it, bd.chain);
 }
 
+// ---- which chains take the look-ahead form (phase 2, chain_lookahead) -------------------------------------------------------
+// The longest chains ARE the iteration's critical path.  For popularity ranks below la_ranks phase 1 also builds, for every block
+// but the chain's first, the block of lr L that couples it to the block before it (gram_cross_block), and phase 2 then needs the
+// item row for nothing on its dependent path.  The chain's blocks must lie below la_cap (the cross blocks' buffer).
+__device__ __forceinline__ bool chain_is_lookahead(const BsIteration &it, int chain, const BsChainDesc &cd) {
+    const int nblk = (cd.len + kB - 1) / kB;
+    return chain < it.la_ranks && nblk >= 2 && cd.blk0 + nblk <= it.la_cap;
+}
+
+// ---- phase 1, look-ahead chains: the cross block N_i = lr L[block i][block i - 1] ---------------------------------------------------
+//     N_i[k][j] = lr (c^(63 + k - j) + a^(63 + k - j) (p_(i,k) . p_(i-1,j)))        (tests/test_blocksolve_algebra.py, lookahead_chain)
+// One workgroup of four wavefronts, one 32 x 32 tile each; both MFMA operands are "lane = row, lane half = half of the columns", so
+// every lane reads its two rows' halves straight from memory into registers -- no LDS.  Rows of links past the block's end are zero.
+__device__ __forceinline__ void gram_cross_block(const SgdArgs &a, const BsIteration &it, int g) {
+    const BsBlockDesc bd = it.blocks[g];
+    if (bd.n_valid == 0 || bd.m == 0 || !chain_is_lookahead(it, bd.chain, it.chains[bd.chain])) return;  // workgroup uniform
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, k = lane & 31, h = lane >> 5;
+    const int rt = wave >> 1, ct = wave & 1;  // tile: rows 32 rt .. of this block, columns 32 ct .. of the previous one
+    const int nslots = a.nslots, S0 = (nslots + 1) >> 1;
+    const int xc = static_cast<int>(it.vals[bd.pos0 + min(kH * rt + k, bd.n_valid - 1)] >> 32);
+    const int xp = static_cast<int>(it.vals[bd.pos0 - kB + kH * ct + k] >> 32);
+    const f32x4 *ra = reinterpret_cast<const f32x4 *>(a.P + static_cast<size_t>(xc) * a.ldp);
+    const f32x4 *rb = reinterpret_cast<const f32x4 *>(a.P + static_cast<size_t>(xp) * a.ldp);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int c = 0; c < S0; c += 4) {
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // unconditional loads at clamped addresses, zeroed by a select
+            const int slot = h * S0 + c + i;
+            const bool ok = c + i < S0 && slot < nslots;
+            const f32x4 t0 = ra[min(slot, nslots - 1)], t1 = rb[min(slot, nslots - 1)];
+            va[i] = ok ? t0 : f32x4{0.f, 0.f, 0.f, 0.f};
+            vb[i] = ok ? t1 : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i][e], vb[i][e], acc, 0, 0, 0);
+    }
+    const float lr = a.h.lr;
+    float *dst = it.Nbuf + static_cast<size_t>(g) * kBsCrossFloats;
+    const int j = kH * ct + k;  // this lane's column: link j of the previous block
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int i = kH * rt + acc_row(reg, h);  // link i of this block
+        const int d = kB - 1 + i - j;             // 0 .. 126
+        const float v = lr * (it.tables[kTabCpow + d] + it.tables[kTabApow + d] * acc[reg]);
+        dst[i * kB + j] = i < bd.n_valid ? v : 0.f;
+    }
+}
+
 // ---- phase 1: the inverse factor of every block --------------------------------------------------------------------
 // One workgroup of four wavefronts per block.  The 64 user rows are gathered with coalesced 128-byte pieces into LDS
 // (odd row stride: a column read is conflict free), 16 rows per wavefront, all of a lane's loads in flight together.
@@ -266,9 +324,8 @@ __host__ __device__ inline size_t gram_tile_float4s(int nslots) { return static_
 __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration it) {
     extern __shared__ float4 bs_smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = blockIdx.x;
+    const int g = static_cast<int>(blockIdx.x) - it.la_grid;  // (the first la_grid workgroups of the launch: the cross blocks)
     WaveStamp stamp(it);
-    const BsBlockDesc bd = it.blocks[g];
     // (every workgroup counts itself through, used or not: the side stream's gate waits for the whole grid)
     struct Through {
         unsigned long long *count;
@@ -278,10 +335,20 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
                 __hip_atomic_fetch_add(count + 16 * (blockIdx.x & 31), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } through_count{it.gram_done};
+    if (g < 0) {
+        // the cross blocks of the look-ahead chains, whose blocks are the first of the table; dispatched first: they have nothing to
+        // wait for and end long before the inversions do
+        const BsChainDesc last = it.chains[it.la_ranks - 1];
+        const int la_end = min(last.blk0 + (last.len + kB - 1) / kB, it.la_cap);
+        for (int gb = g + it.la_grid; gb < la_end; gb += it.la_grid) gram_cross_block(a, it, gb);
+        stamp.done(it, 7, 4 * (g + it.la_grid) + wave);
+        return;
+    }
+    const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) {
         // The last workgroup of the grid (always an unused block: the grid is an upper bound) keeps this launch alive until
         // every chain's workgroup of phase 2 has started: phase 3, queued behind this launch, then finds them on their CUs.
-        if (it.concurrent && g == static_cast<int>(gridDim.x) - 1 && threadIdx.x == 0 && !(it.dbg & 2)) {
+        if (it.concurrent && g == it.max_blocks - 1 && threadIdx.x == 0 && !(it.dbg & 2)) {
             const unsigned long long t0 = wall_clock64();
             unsigned polls = 0;
             while (ld_agent(it.solve_started) < it.started_target) {
@@ -481,6 +548,9 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
 //   loader: streams each block's 64 user rows, factor tiles and base errors global -> registers -> LDS ring of two slots,
 //           kDepth blocks in flight in the register file: a chain of n links moves n * (4f + 196) bytes through ONE
 //           CU's load path, and that is what a long chain takes.
+// (the plain form's copy of the decay tables in LDS: powers 0 .. 64 only -- at 63 slots a row its LDS has no room for more)
+constexpr int kSolTabStride = kB + 1, kSolTabFloats = 4 * kSolTabStride;
+constexpr int kSolTabAdel = 0, kSolTabCdel = kSolTabStride, kSolTabApow = 2 * kSolTabStride, kSolTabCpow = 3 * kSolTabStride;
 constexpr int kRing = 2;   // LDS slots: the block being solved and the next one
 constexpr int kDepth = 4;  // blocks a loader keeps in flight
 
@@ -498,7 +568,7 @@ __host__ __device__ inline int solve_slot_f4(int nslots) { return kB * (nslots |
 // after the ring: the item row (4 * sw + 8 float4, zero beyond the row), the partial dots and errors, four copies of rhs
 // and w, the decay tables, a row of zeros
 __host__ __device__ inline size_t solve_lds_bytes(int nslots, int sw) {
-    return (static_cast<size_t>(kRing) * solve_slot_f4(nslots) + 4 * sw + 8 + 2 * kB + 8 * kB / 4 + (kBsTableFloats + 3) / 4 + 8 + 1) * 16;
+    return (static_cast<size_t>(kRing) * solve_slot_f4(nslots) + 4 * sw + 8 + 2 * kB + 8 * kB / 4 + (kSolTabFloats + 3) / 4 + 8 + 1) * 16;
 }
 
 // The four solver wavefronts meet twice inside a block; s_barrier would drag the loaders along (their work of an interval
@@ -1049,11 +1119,11 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
     float4 *epart = dpart + kB;                                    // [kB]: link k's four partial errors
     float *rbuf = reinterpret_cast<float *>(epart + kB) + w * kB;  // [4][kB]: rhs, one copy per wavefront
     float *wbuf = reinterpret_cast<float *>(epart + kB) + (4 + w) * kB;  // [4][kB]: w, one copy per wavefront
-    float *tab = reinterpret_cast<float *>(epart + kB) + 8 * kB;   // [kBsTableFloats]
-    float4 *zrow = reinterpret_cast<float4 *>(tab) + (kBsTableFloats + 3) / 4;  // [8] zeros
+    float *tab = reinterpret_cast<float *>(epart + kB) + 8 * kB;   // [kSolTabFloats]
+    float4 *zrow = reinterpret_cast<float4 *>(tab) + (kSolTabFloats + 3) / 4;  // [8] zeros
     unsigned *meet = reinterpret_cast<unsigned *>(zrow + 8);                    // [1] arrivals at the solvers' meeting points
     if (w == 0) {
-        for (int i = k; i < kBsTableFloats; i += 64) tab[i] = it.tables[i];
+        for (int i = k; i < kSolTabFloats; i += 64) tab[i] = it.tables[(i / kSolTabStride) * kBsTableStride + i % kSolTabStride];
         if (k < 8) zrow[k] = zero4();
         if (k == 0) *meet = 0u;
     }
@@ -1113,9 +1183,9 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
             for (int t = 0; t < 4; ++t) mq[t] = lds4(mrow + t);
             base = Mt[k * kMS + kH];
             const int back = max(n - 1 - k, 0);
-            adel_k = tab[kTabAdel + k], cdel_k = tab[kTabCdel + k];
-            apr = tab[kTabApow + back], cpr = tab[kTabCpow + back];
-            adel_n = tab[kTabAdel + n], cdel_n = tab[kTabCdel + n];
+            adel_k = tab[kSolTabAdel + k], cdel_k = tab[kSolTabCdel + k];
+            apr = tab[kSolTabApow + back], cpr = tab[kSolTabCpow + back];
+            adel_n = tab[kSolTabAdel + n], cdel_n = tab[kSolTabCdel + n];
             // (A) this wavefront's quarter of every link's row against the item row; slots beyond the row multiply the
             // item row's zero padding
             const float4 *prow = tile + k * RS;
@@ -1260,6 +1330,465 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
     if (CONC) __syncthreads();  // pairs with the loaders' last barrier
 }
 
+// ---- phase 2, the longest chains: the look-ahead form ---------------------------------------------------------------------------
+// The plain form above is a ring of three dependent mat-vecs per block, (A) d = P q -> (B) e = M rhs -> (C) q <- a^n q + P^T w, split
+// four ways with two meeting points: 1.4-1.6 us per block, and the hottest chain (31 blocks on the ML-20M shape) is more than half
+// of an iteration.  With the cross block N_i = lr L[block i][block i - 1] from phase 1 (gram_cross_block) the errors obey
+//     e_i = M_i (pre_i - N_i e_(i-1)),     pre_i[k] = base_i[k] - c^(k+64) b_(i-1) - a^(k+64) (p_(i,k) . q_(i-1))
+// (tests/test_blocksolve_algebra.py, lookahead_chain): the only DEPENDENT work per block is two 64 x 64 mat-vecs, done by ONE
+// wavefront with no partner to meet; the item row follows one block behind -- q_(i+1) from e_i, then (p . q_(i+1)) for block
+// i + 2 -- on other wavefronts, with two blocks' time to do it in.  Eight wavefronts, fixed roles, NO workgroup barrier after the
+// prologue; every hand-over is a counter in LDS that only its producer writes (LDS operations of a wavefront complete in order:
+// whoever sees the count sees the data written before it):
+//   wavefront 0   chain   e_i: record i (M_i, N_i, base) LDS -> registers, t0 = N_i e_(i-1), waits for g_i, e_i = M_i (pre_i - t0),
+//                         publishes e_i and w_i = lr a^(n-1-k) e_i[k]; carries the item bias
+//   wavefronts 1-2 state  q_(i+1) = a^n q_i + sum_k w_i[k] p_(i,k): every other pass of 8 slots each, lane = (slot, group of 8 links);
+//                         q_i goes to phase 3 (qstart)
+//   wavefront 3   dots    g_i[k] = p_(i,k) . q_(max(i-1, 0)): lane = link
+//   wavefronts 4-7 loaders  block i (i = w mod 4): its 64 user rows memory -> registers -> P ring (three slots), then its record
+//                         memory -> registers -> record ring (two slots).  One block at a time per wavefront, waiting with its data
+//                         in registers for the slot: no load is in flight across a wait, so the compiler's s_waitcnt
+//                         bookkeeping has nothing to get wrong; four wavefronts cover the latency.
+// NSM: float4 slots per row the instantiation has registers for (nslots <= NSM <= 31: the rings fit the 160 KB of LDS).
+constexpr int kLaPRing = 3, kLaRRing = 2, kLaDepth = 2;
+constexpr int kLaNS4 = 17;                                  // float4 per row of the cross block in LDS (odd: conflict-free row reads)
+constexpr int kLaRec4 = 3 * kH * kMS / 4 + kB * kLaNS4;     // a record in LDS: three factor tiles (base errors in column 32), the cross block
+constexpr int kLaQ4 = 32;                                   // float4 per item-row buffer
+constexpr int kLaMaxSlots = 29;
+__host__ __device__ inline bool la_supported(int nslots) { return nslots >= 1 && nslots <= kLaMaxSlots; }
+__host__ __device__ inline size_t la_lds_bytes(int nslots) {
+    return (static_cast<size_t>(kLaPRing) * kB * (nslots | 1) + kLaRRing * kLaRec4 + 2 * kLaQ4 + 7 * kB / 4 + (kBsTableFloats + 3) / 4 + 4 + 64) * 16;
+}
+
+enum { kSyC0 = 0, kSyC1 = 1, kSyE = 2, kSyG = 3, kSyLdP = 4, kSyLdR = 8, kSyR = 12, kSyAbort = 13 };  // (C0 | C1, LdP[4], LdR[4]: read together)
+
+// waits until *word >= target; bounded: gives up after 2 s (or as soon as another wait of the workgroup has), sets the status word
+__device__ __forceinline__ void la_wait(unsigned *sy, int word, unsigned target, const BsIteration &it, unsigned long long *waited = nullptr) {
+#if CU2REC_BS_TRACE
+    const unsigned long long tw = wall_clock64();
+#endif
+    unsigned polls = 0;
+    unsigned long long t0 = 0;
+    while (__hip_atomic_load(sy + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 1023u) == 0) {
+            if (t0 == 0) t0 = wall_clock64();
+            if (__hip_atomic_load(sy + kSyAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks) {
+                __hip_atomic_store(sy + kSyAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");  // nothing behind the wait is read in front of it
+#if CU2REC_BS_TRACE
+    if (waited) *waited += wall_clock64() - tw;
+#endif
+}
+__device__ __forceinline__ void la_post(unsigned *sy, int word, unsigned value) {
+    asm volatile("" ::: "memory");  // everything written so far is issued in front of the count
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(sy + word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ... until all four counters sy[word .. word + 3] (16-byte aligned) have reached target: ONE LDS read per poll
+__device__ __forceinline__ void la_wait4(unsigned *sy, int word, unsigned target, const BsIteration &it, unsigned long long *waited = nullptr) {
+#if CU2REC_BS_TRACE
+    const unsigned long long tw = wall_clock64();
+#endif
+    unsigned polls = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        // (an LDS pointer by type: through a generic volatile pointer this was a FLAT load that waited for every global store in flight)
+        const u32x4 v = __builtin_nontemporal_load((const __attribute__((address_space(3))) u32x4 *)(sy + word));
+        asm volatile("" ::: "memory");
+        if (min(min(v.x, v.y), min(v.z, v.w)) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 1023u) == 0) {
+            if (t0 == 0) t0 = wall_clock64();
+            if (__hip_atomic_load(sy + kSyAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks) {
+                __hip_atomic_store(sy + kSyAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+#if CU2REC_BS_TRACE
+    if (waited) *waited += wall_clock64() - tw;
+#endif
+}
+// ... until both sy[word] and sy[word + 1] (8-byte aligned) have
+__device__ __forceinline__ void la_wait2(unsigned *sy, int word, unsigned target, const BsIteration &it, unsigned long long *waited = nullptr) {
+#if CU2REC_BS_TRACE
+    const unsigned long long tw = wall_clock64();
+#endif
+    unsigned polls = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+        typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+        const u32x2v v = __builtin_nontemporal_load((const __attribute__((address_space(3))) u32x2v *)(sy + word));
+        asm volatile("" ::: "memory");
+        if (min(v.x, v.y) >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 1023u) == 0) {
+            if (t0 == 0) t0 = wall_clock64();
+            if (__hip_atomic_load(sy + kSyAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks) {
+                __hip_atomic_store(sy + kSyAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+#if CU2REC_BS_TRACE
+    if (waited) *waited += wall_clock64() - tw;
+#endif
+}
+
+template <int NSM>
+__device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIteration &it, float4 *smem, WaveStamp &stamp, int chain,
+                                                const BsChainDesc &cd) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nslots = a.nslots, RS = nslots | 1;
+    const int begin = cd.begin, len = cd.len, nblk = (len + kB - 1) / kB, g0 = cd.blk0, y = cd.item;
+    float4 *pring = smem;                                        // [kLaPRing][kB][RS]
+    float4 *rring = pring + kLaPRing * kB * RS;                  // [kLaRRing][kLaRec4]
+    float4 *qbuf = rring + kLaRRing * kLaRec4;                   // [2][kLaQ4] the item row in front of block i: buffer i & 1, zero beyond the row
+    float *wbuf = reinterpret_cast<float *>(qbuf + 2 * kLaQ4);   // [2][kB] w_i
+    float *ebl = wbuf + 2 * kB;                                  // [2][kB] e_i
+    float *tbuf = ebl + 2 * kB;                                  // [kB]    the chain wavefront's own right-hand side
+    float *gbuf = tbuf + kB;                                     // [2][kB] g_i
+    float *tab = gbuf + 2 * kB;                                  // [kBsTableFloats]
+    unsigned *sy = reinterpret_cast<unsigned *>(tab + ((kBsTableFloats + 3) & ~3));  // [16] the counters
+    f32x4 *sink = reinterpret_cast<f32x4 *>(sy + 16);                               // [64] where the loaders' surplus lanes store
+    const float lr = a.h.lr;
+
+    if (wave >= 4) {
+        // ---------------------------------------------------------------------------------------------------------- loaders
+        // wavefront 4 + w: quarter w of every block's row image (float4 numbers 64 (w NQ + j) + lane, j < NQ) and its share of the
+        // block's record (w 0, 1: the factor tiles, w 0 the base errors too; w 2, 3: the cross block), kLaDepth blocks in flight in
+        // registers.  Every load and store is unconditional (clamped addresses, a sink in LDS for the surplus lanes): a branch
+        // around a load makes the compiler wait for everything in flight.
+        const int w = wave - 4;
+        unsigned long long wt[2] = {0, 0};
+        constexpr int NQ = (NSM + 3) / 4;
+        const int idx0 = w * kB * NQ + lane;
+        const int row0 = idx0 / nslots, slot0 = idx0 - row0 * nslots;
+        const int drow = kB / nslots, dslot = kB - drow * nslots;
+        auto load_val = [&](int i) -> uint64_t { return it.vals[begin + min(kB * i + lane, len - 1)]; };
+        struct LaStage {
+            f32x4 v[NQ], r[8];
+            uint64_t next_val;
+        };
+        auto issue = [&](LaStage &st, int i, uint64_t val) {  // block i (clamped: past the chain's end the last block again, never committed)
+            const int ic = min(i, nblk - 1);
+            st.next_val = load_val(min(i + kLaDepth, nblk - 1));
+            const int x = static_cast<int>(val >> 32);
+            int row = row0, slot = slot0;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {  // past the block's image (float4 number >= 64 nslots): the last row again
+                const int xr = __shfl(x, min(row, kB - 1));
+                st.v[j] = reinterpret_cast<const f32x4 *>(a.P + static_cast<size_t>(xr) * a.ldp)[slot];
+                slot += dslot, row += drow;
+                if (slot >= nslots) slot -= nslots, ++row;
+            }
+            // the record: 768 float4 of factor tiles + 16 of base errors (Mbuf), 1,024 of the cross block (Nbuf; block 0 has none:
+            // block 1's, never used)
+            const f32x4 *src = w < 2 ? reinterpret_cast<const f32x4 *>(it.Mbuf + static_cast<size_t>(g0 + ic) * kBsRecFloats) + 384 * w
+                                     : reinterpret_cast<const f32x4 *>(it.Nbuf + static_cast<size_t>(g0 + max(ic, 1)) * kBsCrossFloats) + 512 * (w - 2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int at = w < 2 && j >= 6 ? 768 - 384 * w + (lane & 15) : lane + 64 * j;  // (w < 2: six tiles' pieces, then the base errors)
+                st.r[j] = src[at];
+            }
+        };
+        auto commit = [&](const LaStage &st, int i) {
+            if (i >= kLaPRing) {  // the slot's last reader: the state wavefronts, block i - 3
+                la_wait2(sy, kSyC0, static_cast<unsigned>(i - kLaPRing + 1), it, &wt[0]);
+            }
+            {
+                f32x4 *tile = reinterpret_cast<f32x4 *>(pring + (i % kLaPRing) * kB * RS);
+                int row = row0, slot = slot0;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {  // past the image: this lane's float4 of the sink
+                    f32x4 *dst = row < kB ? tile + row * RS + slot : sink + lane;
+                    *dst = kB * i + row < len ? st.v[j] : z;
+                    slot += dslot, row += drow;
+                    if (slot >= nslots) slot -= nslots, ++row;
+                }
+            }
+            la_post(sy, kSyLdP + w, static_cast<unsigned>(i + 1));
+            if (i >= kLaRRing) la_wait(sy, kSyR, static_cast<unsigned>(i - kLaRRing + 1), it, &wt[1]);  // the chain wavefront has taken record i - 2
+            f32x4 *rr = reinterpret_cast<f32x4 *>(rring + (i % kLaRRing) * kLaRec4);
+            if (w < 2) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int idx = 384 * w + lane + 64 * j;  // tile idx >> 8, row (idx >> 3) & 31, float4 idx & 7
+                    rr[((idx >> 8) * kH + ((idx >> 3) & 31)) * (kMS / 4) + (idx & 7)] = st.r[j];
+                }
+                if (w == 0 && lane < 16) {  // float4 number 768 + lane: the base errors of links 4 lane .. 4 lane + 3, column 32 of their rows
+                    float *col = reinterpret_cast<float *>(rr) + (4 * lane) * kMS + kH;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) col[e * kMS] = st.r[6][e];
+                }
+            } else {
+                f32x4 *nl = rr + 3 * kH * kMS / 4;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = 512 * (w - 2) + lane + 64 * j;
+                    nl[(idx >> 4) * kLaNS4 + (idx & 15)] = st.r[j];
+                }
+            }
+            la_post(sy, kSyLdR + w, static_cast<unsigned>(i + 1));
+        };
+        static_assert(kLaDepth == 2, "two stages: four wavefronts x two blocks x 15 KB in flight");
+        LaStage st[kLaDepth];
+        {
+            uint64_t v0[kLaDepth];
+#pragma unroll
+            for (int t = 0; t < kLaDepth; ++t) v0[t] = load_val(min(t, nblk - 1));
+#pragma unroll
+            for (int t = 0; t < kLaDepth; ++t) issue(st[t], t, v0[t]);
+        }
+        __syncthreads();  // the prologue's one barrier: counters and tables are set
+        for (int m0 = 0; m0 < nblk; m0 += kLaDepth) {
+#pragma unroll
+            for (int u = 0; u < kLaDepth; ++u) {
+                const int i = m0 + u;
+                if (i < nblk) commit(st[u], i);  // wavefront uniform
+                issue(st[u], i + kLaDepth, st[u].next_val);
+            }
+        }
+        stamp.span(0, wt[0]);
+        stamp.span(1, wt[1]);
+        stamp.span(2, 1);
+        stamp.span(3, 1);
+        stamp.done(it, 3, chain * 4 + w);
+        return;
+    }
+
+    if (wave == 3) {
+        // ------------------------------------------------------------------------------------------------------------- dots
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(2);
+        unsigned long long wt[2] = {0, 0};
+        for (int i = 0; i < nblk; ++i) {
+            const int src = max(i - 1, 0);
+            la_wait4(sy, kSyLdP, static_cast<unsigned>(i + 1), it, &wt[0]);
+            if (src > 0) la_wait2(sy, kSyC0, static_cast<unsigned>(src), it, &wt[1]);
+            const float4 *prow = pring + (i % kLaPRing) * kB * RS + lane * RS;
+            const float4 *qv = qbuf + (src & 1) * kLaQ4;
+            // two halves, every read of a half in flight before its first product: one LDS latency per half, not one per slot
+            constexpr int NH2 = (NSM + 1) / 2;
+            f32x2 acc[4] = {dup2(0.f), dup2(0.f), dup2(0.f), dup2(0.f)};
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x4 pv[NH2], qq[NH2];
+#pragma unroll
+                for (int j = 0; j < NH2; ++j) {
+                    pv[j] = lds4(prow + min(hh * NH2 + j, nslots - 1));
+                    qq[j] = lds4(qv + min(hh * NH2 + j, kLaQ4 - 1));  // (the item row's buffer is zero beyond the row)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NH2; ++j) {
+                    if (hh * NH2 + j < NSM) {
+                        acc[2 * (j & 1)] = fma2(lo2(pv[j]), lo2(qq[j]), acc[2 * (j & 1)]);
+                        acc[2 * (j & 1) + 1] = fma2(hi2(pv[j]), hi2(qq[j]), acc[2 * (j & 1) + 1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc[0] += acc[2];
+            acc[1] += acc[3];
+            const f32x2 ds = acc[0] + acc[1];
+            gbuf[(i & 1) * kB + lane] = ds.x + ds.y;
+            la_post(sy, kSyG, static_cast<unsigned>(i + 1));
+        }
+        stamp.span(0, wt[0]);
+        stamp.span(1, wt[1]);
+        stamp.span(2, 1);
+        stamp.span(3, 1);
+        stamp.done(it, 2, chain * 4 + 3);
+        return;
+    }
+
+    if (wave >= 1) {
+        // ------------------------------------------------------------------------------------------------------------ state
+        const int c = wave - 1;
+        constexpr int NP = (NSM + 7) / 8, NPW = (NP + 1) / 2;  // passes of 8 slots; this wavefront: passes c, c + 2, ...
+        const int sl = lane & 7, kg = lane >> 3;
+        f32x4 q4[NPW];
+        const f32x4 *qsrc = reinterpret_cast<const f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
+#pragma unroll
+        for (int pp = 0; pp < NPW; ++pp) {
+            const int slot = 8 * (2 * pp + c) + sl;
+            const f32x4 v = qsrc[min(slot, nslots - 1)];
+            q4[pp] = slot < nslots ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kg < 2 && slot < kLaQ4) *reinterpret_cast<f32x4 *>(qbuf + kg * kLaQ4 + slot) = kg == 0 ? q4[pp] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(2);
+        unsigned long long wt[1] = {0};
+        for (int i = 0; i < nblk; ++i) {
+            const int n = min(kB, len - kB * i);
+            const float adel_n = tab[kTabAdel + n];
+            la_wait(sy, kSyE, static_cast<unsigned>(i + 1), it, &wt[0]);
+            const float4 *tile = pring + (i % kLaPRing) * kB * RS;
+            const float4 *wv = reinterpret_cast<const float4 *>(wbuf + (i & 1) * kB) + 2 * kg;
+            float *qdst = it.qstart + static_cast<size_t>(g0 + i) * a.ldq;
+            const f32x4 wb0 = lds4(wv), wb1 = lds4(wv + 1);
+            f32x4 tb[NPW][8];  // every read of the block in flight before the first product
+#pragma unroll
+            for (int pp = 0; pp < NPW; ++pp) {
+                const float4 *colp = tile + (8 * kg) * RS + min(8 * (2 * pp + c) + sl, nslots - 1);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) tb[pp][r] = lds4(colp + r * RS);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pp = 0; pp < NPW; ++pp) {
+                const int slot = 8 * (2 * pp + c) + sl;
+                const bool ok = slot < nslots;
+                if (ok && kg == 0) *reinterpret_cast<f32x4 *>(qdst + 4 * slot) = q4[pp];  // the row in front of block i: phase 3's
+                f32x2 ulo = dup2(0.f), uhi = dup2(0.f);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const f32x2 ww = dup2(r < 4 ? wb0[r & 3] : wb1[r & 3]);
+                    ulo = fma2(ww, lo2(tb[pp][r]), ulo);
+                    uhi = fma2(ww, hi2(tb[pp][r]), uhi);
+                }
+                float u[4] = {ulo.x, ulo.y, uhi.x, uhi.y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {  // the eight groups: lanes l ^ 8, l ^ 16, l ^ 32
+                    u[e] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u[e]), 0x128, 0xf, 0xf, false));  // row_ror:8
+                    u[e] = half_sum(row_pair_sum(u[e]));
+                }
+                const f32x4 qo = q4[pp];
+                q4[pp] = ok ? f32x4{(qo.x - adel_n * qo.x) + u[0], (qo.y - adel_n * qo.y) + u[1], (qo.z - adel_n * qo.z) + u[2],
+                                    (qo.w - adel_n * qo.w) + u[3]}
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok && kg == 0) *reinterpret_cast<f32x4 *>(qbuf + ((i + 1) & 1) * kLaQ4 + slot) = q4[pp];
+            }
+            la_post(sy, kSyC0 + c, static_cast<unsigned>(i + 1));
+        }
+        if (kg == 0) {
+            f32x4 *qd = reinterpret_cast<f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
+#pragma unroll
+            for (int pp = 0; pp < NPW; ++pp) {
+                const int slot = 8 * (2 * pp + c) + sl;
+                if (slot < nslots) qd[slot] = q4[pp];
+            }
+        }
+        stamp.span(0, wt[0]);
+        stamp.span(1, 1);
+        stamp.span(2, 1);
+        stamp.span(3, 1);
+        stamp.done(it, 2, chain * 4 + wave);
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------ chain
+    const int k = lane;
+    for (int i = k; i < kBsTableFloats; i += 64) tab[i] = it.tables[i];
+    if (k < 16) sy[k] = 0u;
+    float b_cur = a.item_bias[y], b_prev = b_cur;
+    asm volatile("" ::"v"(b_cur));
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(3);
+    stamp.mark(it, 0);
+    const int kr = k & 31;
+    const bool upper = k >= kH;
+    unsigned long long wt[2] = {0, 0};
+    // record i in registers one block ahead: this lane's row of M (links 0-31: [M11 row | 0], links 32-63: [M21 row | M22 row]), its
+    // row of the cross block, its base error -- read while the other wavefronts work on the item row, not on the dependent path
+    f32x4 m4[16], n4[16];
+    float base;
+    auto take_record = [&](int i) {
+        la_wait4(sy, kSyLdR, static_cast<unsigned>(i + 1), it, &wt[0]);
+        const float4 *rr = rring + (i % kLaRRing) * kLaRec4;
+        const float *Mt = reinterpret_cast<const float *>(rr);
+        const float4 *mlo = reinterpret_cast<const float4 *>(Mt + ((upper ? kH : 0) + kr) * kMS);
+        const float4 *mhi = reinterpret_cast<const float4 *>(Mt + (2 * kH + kr) * kMS);
+        const float4 *nrow = rr + 3 * kH * kMS / 4 + k * kLaNS4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            m4[j] = lds4(mlo + j);
+            const f32x4 hi = lds4(mhi + j);
+            m4[8 + j] = upper ? hi : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) n4[j] = lds4(nrow + j);
+        base = Mt[k * kMS + kH];
+        la_post(sy, kSyR, static_cast<unsigned>(i + 1));  // (the slot's reads are issued: LDS serves a wavefront in order)
+    };
+    take_record(0);
+    for (int i = 0; i < nblk; ++i) {
+        const int n = min(kB, len - kB * i);
+        // t0 = N_i e_(i-1): this lane's row of the cross block against the errors of the block before (all 16 broadcast reads in
+        // flight before the first product)
+        f32x2 tacc[2] = {dup2(0.f), dup2(0.f)};
+        if (i > 0) {
+            const float4 *ev = reinterpret_cast<const float4 *>(ebl + ((i - 1) & 1) * kB);
+            f32x4 e4[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) e4[j] = lds4(ev + j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                tacc[0] = fma2(lo2(n4[j]), lo2(e4[j]), tacc[0]);
+                tacc[1] = fma2(hi2(n4[j]), hi2(e4[j]), tacc[1]);
+            }
+        }
+        const f32x2 ts = tacc[0] + tacc[1];
+        const float t0 = ts.x + ts.y;
+        // pre_i from the state in front of block max(i - 1, 0)
+        const int kd = i > 0 ? k + kB : k;
+        const float adel_k = tab[kTabAdel + kd], cdel_k = tab[kTabCdel + kd];
+        const float bsrc = i > 0 ? b_prev : b_cur;
+        la_wait(sy, kSyG, static_cast<unsigned>(i + 1), it, &wt[1]);
+        const float gd = gbuf[(i & 1) * kB + k];
+        const float pre = k < n ? (base - (bsrc - cdel_k * bsrc)) - (gd - adel_k * gd) : 0.f;
+        tbuf[k] = pre - t0;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        f32x2 eacc[2] = {dup2(0.f), dup2(0.f)};
+        {
+            const float4 *tv = reinterpret_cast<const float4 *>(tbuf);
+            f32x4 t4[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) t4[j] = lds4(tv + j);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                eacc[0] = fma2(lo2(m4[j]), lo2(t4[j]), eacc[0]);
+                eacc[1] = fma2(hi2(m4[j]), hi2(t4[j]), eacc[1]);
+            }
+        }
+        const f32x2 es = eacc[0] + eacc[1];
+        const float e = k < n ? es.x + es.y : 0.f;
+        const int back = max(n - 1 - k, 0);
+        ebl[(i & 1) * kB + k] = e;
+        wbuf[(i & 1) * kB + k] = k < n ? lr * tab[kTabApow + back] * e : 0.f;
+        la_post(sy, kSyE, static_cast<unsigned>(i + 1));
+        it.ebuf[static_cast<size_t>(g0 + i) * kB + k] = e;
+        if (i + 1 < nblk) take_record(i + 1);  // wavefront uniform
+        // the item bias behind block i
+        const float bs = row_sum16(k < n ? lr * tab[kTabCpow + back] * e : 0.f);
+        const float cdel_n = tab[kTabCdel + n];
+        const float b_next = (b_cur - cdel_n * b_cur) + ((lane_value(bs, 0) + lane_value(bs, 16)) + (lane_value(bs, 32) + lane_value(bs, 48)));
+        b_prev = b_cur;
+        b_cur = b_next;
+    }
+    stamp.span(1, wt[0]);
+    stamp.span(2, wt[1]);
+    stamp.mark(it, 3);
+    if (k == 0) a.item_bias[y] = b_cur;
+    stamp.done(it, 2, chain * 4);
+}
+
 // Concurrent topology: the grid is at most half the CUs (workgroup g takes chains g, g + grid, ...: popularity ranks, so the long
 // chains come first and get a workgroup each): phase 1 runs at the same time and needs CUs of its own -- a chain's workgroup (2 x ~220
 // registers per SIMD, 80-160 KB of LDS) leaves no room for a phase-1 workgroup beside it, and chains waiting on every CU for
@@ -1278,6 +1807,12 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
         const BsChainDesc cd = it.chains[chain];
         // a long chain's head only (see chain_is_affine); the form takes rows of at most 31 slots (bs_affine_supported): compiled
         // out of the wider instantiations
+        if constexpr (SW <= 8) {
+            if (chain_is_lookahead(it, chain, cd)) {  // workgroup uniform
+                chain_lookahead<(4 * SW < kLaMaxSlots ? 4 * SW : kLaMaxSlots)>(a, it, bs_smem, stamp, chain, cd);
+                return;
+            }
+        }
         bool head_only = false;
         if constexpr (SW <= 8) head_only = cd.len > 0 && chain_is_affine(it, chain);  // workgroup uniform
         solve_chain<SW, false>(a, it, bs_smem, stamp, chain, BsChainDesc{cd.begin, head_only ? it.aff_head * kB : cd.len, cd.blk0, cd.item}, head_only);
@@ -1478,8 +2013,9 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
 
 template <int SW>
 void launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
-    const size_t lds = std::max(solve_lds_bytes(a.nslots, SW),
-                                it.aff_min_blocks > 0 ? std::max(affine_lds_bytes(a.nslots), affine_build_lds_bytes(a.nslots)) : static_cast<size_t>(0));
+    size_t lds = std::max(solve_lds_bytes(a.nslots, SW),
+                          it.aff_min_blocks > 0 ? std::max(affine_lds_bytes(a.nslots), affine_build_lds_bytes(a.nslots)) : static_cast<size_t>(0));
+    if (it.la_ranks > 0) lds = std::max(lds, la_lds_bytes(a.nslots));
     if (it.concurrent) {
         ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, true>));
         hipLaunchKernelGGL((bs_solve_kernel<SW, true>), dim3(bs_solve_grid(it.n_hot)), dim3(512), lds, stream, a, it);
@@ -1565,6 +2101,7 @@ void bs_check_fault() {
 }
 
 bool bs_supported(int nslots) { return nslots >= 1 && nslots <= kBsMaxSlots; }
+bool bs_lookahead_supported(int nslots) { return la_supported(nslots); }
 
 int bs_compute_units() {
     static std::mutex mutex;
@@ -1580,7 +2117,7 @@ int bs_compute_units() {
 int bs_solve_grid(int n_hot) { return std::max(1, std::min(n_hot, bs_compute_units() / 2)); }
 
 void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream) {
-    hipLaunchKernelGGL(bs_tables_kernel, dim3(1), dim3(128), 0, stream, h, tables);
+    hipLaunchKernelGGL(bs_tables_kernel, dim3(1), dim3(192), 0, stream, h, tables);
 }
 
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
@@ -1597,8 +2134,9 @@ void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream,
     ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_gram_kernel));
     // `stop`: an event completed by the kernel's own completion signal (hipExtLaunchKernelGGL) -- a hipEventRecord behind the
     // launch is a marker packet of its own and held the NEXT launch of the stream back by 6-7 us (kernel traces, round 3)
-    if (stop) hipExtLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), static_cast<uint32_t>(gram_lds), stream, nullptr, stop, 0, a, it);
-    else hipLaunchKernelGGL(bs_gram_kernel, dim3(it.max_blocks), dim3(256), gram_lds, stream, a, it);
+    const int grid = it.max_blocks + (it.la_ranks > 0 ? it.la_grid : 0);
+    if (stop) hipExtLaunchKernelGGL(bs_gram_kernel, dim3(grid), dim3(256), static_cast<uint32_t>(gram_lds), stream, nullptr, stop, 0, a, it);
+    else hipLaunchKernelGGL(bs_gram_kernel, dim3(grid), dim3(256), gram_lds, stream, a, it);
     CU2REC_HIP(hipGetLastError());
 }
 

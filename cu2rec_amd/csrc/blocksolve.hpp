@@ -12,10 +12,11 @@
 namespace cu2rec {
 
 constexpr int kBsLinks = 64;                        // updates ("links") of a chain per block
-constexpr int kBsTableStride = kBsLinks + 1;        // tables: 1 - a^k, 1 - c^k, a^k, c^k for k = 0..kBsLinks
+constexpr int kBsTableStride = 2 * kBsLinks + 1;    // tables: 1 - a^k, 1 - c^k, a^k, c^k for k = 0..2 kBsLinks (a block and its look-ahead)
 constexpr int kBsTableFloats = 4 * kBsTableStride;
 constexpr int kBsFactorFloats = 3 * 32 * 32;        // inverse factor of a block: tiles M11, M21, M22 (32 x 32 each, row major)
 constexpr int kBsRecFloats = kBsFactorFloats + kBsLinks;  // a block's record from phase 1: the factor, then r - gb - ub per link
+constexpr int kBsCrossFloats = kBsLinks * kBsLinks;  // look-ahead chains: the 64 x 64 block of lr L that couples a block (rows) to the one before it (columns)
 constexpr int kBsMaxSlots = 63;                     // float4 slots per row the solver has LDS for (n_factors <= 252)
 
 struct BsBlockDesc {  // up to 64 consecutive links of one hot chain
@@ -48,6 +49,13 @@ struct BsIteration {
     float *ebuf;              // [max_blocks][kBsLinks]      error of each hot link
     float *qstart;            // [max_blocks][ldq]           item row at the start of each block
     int max_blocks;
+    // Look-ahead chains (blocksolve.hip, "look-ahead form"): popularity ranks [0, la_ranks) -- the long chains, whose length IS the
+    // iteration's critical path.  Phase 1 also builds the block of lr L that couples each of their blocks to the one before it
+    // (la_grid more workgroups in its launch), and phase 2 runs them with the item row OFF the dependent path.
+    int la_ranks;
+    int la_cap;               // ... whose blocks all lie below la_cap (Nbuf has room for that many; a chain beyond it runs in the plain form)
+    int la_grid;              // workgroups of phase 1's launch that build the cross blocks
+    float *Nbuf;              // [la_cap][kBsCrossFloats]
     // Long chains (at least aff_min_blocks blocks; 0 = none; sequential topology only): every block's effect on the item state
     // (row, bias) as ONE affine map built in phase 1, so that phase 2 is one mat-vec per block with no meeting point
     // (blocksolve.hip, "affine form")
@@ -90,6 +98,7 @@ struct BsIteration {
 void bs_set_stamps(unsigned long long *buf, int cap);
 void bs_get_stamps(unsigned long long **buf, int *cap);
 bool bs_supported(int nslots);
+bool bs_lookahead_supported(int nslots);  // rows of at most 31 float4 slots: the look-ahead form's rings fit the LDS
 int bs_compute_units();       // of the current device
 int bs_solve_grid(int n_hot);  // workgroups of phase 2: one per chain, at most half the CUs of the current device
 // bounded device-side waits report through one status word per device: its address, an asynchronous refresh of the host copy

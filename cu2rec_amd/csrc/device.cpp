@@ -560,6 +560,7 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
 float cu2rec_blocksolve_min_rate(float rate) { return blocksolve_min_rate(rate); }
 int cu2rec_blocksolve_affine_blocks(int blocks) { return blocksolve_affine_blocks(blocks); }
 int cu2rec_blocksolve_affine_head(int blocks) { return blocksolve_affine_head(blocks); }
+int cu2rec_blocksolve_lookahead_blocks(int blocks) { return blocksolve_lookahead_blocks(blocks); }
 
 int cu2rec_csr_blocksolve_items(const cu2rec_csr *train) {
     int n = -1;

@@ -779,6 +779,20 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     while (n_duo_bs < n_cols && n_duo_bs < 4096 && rate[order[n_duo_bs]] >= 12.0) ++n_duo_bs;
     n_duo_bs = std::min(n_duo_bs, (1 << item_bits) - 1);
     max_blocks = n_active / kBsLinks + n_hot_bs + 1;
+    // the look-ahead form of phase 2 (blocksolve.hip): the leading ranks whose chains are expected to be at least
+    // blocksolve_lookahead_blocks() blocks long -- the chains whose length is the iteration's critical path.  Their blocks are
+    // the first of every iteration's block table; la_cap bounds them with room to spare (a chain beyond it: the plain form).
+    la_ranks = 0;
+    la_cap = 0;
+    {
+        const int la_min = blocksolve_lookahead_blocks(-1);
+        double blocks = 0.0;
+        while (la_min > 0 && la_ranks < n_hot_bs && rate[order[la_ranks]] >= static_cast<double>(la_min) * kBsLinks) {
+            blocks += std::ceil(rate[order[la_ranks]] / kBsLinks) + 1.0;
+            ++la_ranks;
+        }
+        if (la_ranks > 0) la_cap = std::min(max_blocks, static_cast<int>(blocks * 1.25) + 4 * la_ranks + 8);
+    }
     n_range_ranks = std::max(std::max(std::min(n_cols, kHotChains), n_duo_bs), n_hot_bs);
     n_range_ranks = std::min(n_range_ranks, (1 << item_bits) - 1);
     for (int slot = 0; slot < 2; ++slot) {
@@ -814,6 +828,7 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         gram_done.zero();
         side_seq.allocate(16);
         side_seq.zero();
+        if (la_cap > 0) Nbuf.allocate(static_cast<size_t>(la_cap) * kBsCrossFloats);
     }
 }
 
@@ -845,6 +860,22 @@ int blocksolve_affine_blocks(int blocks) {
         prev = g_bs_affine_blocks.load();
     }
     if (blocks >= 0) g_bs_affine_blocks.store(blocks);
+    return prev;
+}
+
+namespace {
+std::atomic<int> g_bs_lookahead{-1};  // -1: not yet initialised from the environment
+}
+
+int blocksolve_lookahead_blocks(int blocks) {
+    int prev = g_bs_lookahead.load();
+    if (prev < 0) {
+        const char *env = std::getenv("CU2REC_BLOCKSOLVE_LOOKAHEAD");
+        const int init = env ? std::max(0, std::atoi(env)) : 0;  // opt-in: DESIGN.md section 4, "The look-ahead form"
+        g_bs_lookahead.compare_exchange_strong(prev, init);
+        prev = g_bs_lookahead.load();
+    }
+    if (blocks >= 0) g_bs_lookahead.store(blocks);
     return prev;
 }
 
@@ -1102,6 +1133,12 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.ebuf = ebuf.ptr;
                 it.qstart = qstart.ptr;
                 it.max_blocks = max_blocks;
+                // (sequential topology, rows the rings have LDS for; the affine form and the look-ahead form exclude each other)
+                const bool la_on = !concurrent && aff_min == 0 && la_ranks > 0 && bs_lookahead_supported(a.nslots);
+                it.la_ranks = la_on ? la_ranks : 0;
+                it.la_cap = la_cap;
+                it.la_grid = la_on ? la_cap : 0;
+                it.Nbuf = Nbuf.ptr;
                 it.aff_min_blocks = aff_min;
                 it.aff_head = aff_head;
                 it.aff_cap = aff_cap;
@@ -1142,7 +1179,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                         // wait for each other) ends when the whole grid is through.  Phase 1 is a plain launch then: phase 2 starts
                         // right behind it (an event riding on its completion signal costs 5 us before phase 2).
                         it.gram_done = gram_done.ptr;
-                        gram_done_target += static_cast<unsigned long long>(max_blocks);
+                        gram_done_target += static_cast<unsigned long long>(max_blocks + it.la_grid);
                         started_total += static_cast<unsigned long long>(n_hot_bs);
                         bs_launch_gram(a, it, stream);
                     } else {

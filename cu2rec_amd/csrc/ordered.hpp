@@ -54,6 +54,9 @@ struct OrderedSchedule {
     int n_hot_bs = 0;
     int n_duo_bs = 0;        // ranks [n_hot_bs, n_duo_bs): the ordered mode's two-wave chains, beside the block solves
     int max_blocks = 0;      // blocks of 64 links (kBsLinks) per iteration, upper bound
+    int la_ranks = 0;        // ranks [0, la_ranks): phase 2 in the look-ahead form (blocksolve.hip); their blocks lie below la_cap
+    int la_cap = 0;
+    DeviceBuffer<float> Nbuf;  // [la_cap][kBsCrossFloats] the cross blocks of the look-ahead chains
     int qstart_ld = 0;
     SgdHyper tables_for{};   // hyper-parameters the decay tables were computed from
     bool tables_valid = false;
@@ -95,6 +98,9 @@ float blocksolve_min_rate(float rate);
 float blocksolve_min_rate_base();   // the explicit value, or the default the automatic scaling starts from
 bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwise a schedule scales the default with its set
 
+// chains EXPECTED to be at least this many blocks of 64 links long run phase 2 in the look-ahead form (0: none, the default;
+// schedules created later); blocks < 0 only queries
+int blocksolve_lookahead_blocks(int blocks);
 // chains of at least this many blocks of 64 links take the affine form (0: none); blocks < 0 only queries
 int blocksolve_affine_blocks(int blocks);
 // ... after their first `blocks` blocks in the plain form (>= 1; 0 only queries)

@@ -290,9 +290,18 @@ float cu2rec_blocksolve_min_rate(float rate);
  * set the initial values.  Both return the previous value; blocks < 0 (head: 0) only queries. */
 int cu2rec_blocksolve_affine_blocks(int blocks);
 int cu2rec_blocksolve_affine_head(int blocks);
+/* The longest chains in the look-ahead form (block-solve mode, n_factors <= 116; opt-in, round 4).  Items EXPECTED to collect at
+ * least `blocks` x 64 updates per iteration (the leading popularity ranks): phase 1 also builds, for every block of their chains
+ * but the first, the 64 x 64 block of lr L that couples it to the block before it, and phase 2 runs the chain with
+ *     e_i = M_i (pre_i - N_i e_(i-1))
+ * -- two 64 x 64 matrix-vector products on ONE wavefront as the only dependent work per block, the item row following one block
+ * behind on other wavefronts (no meeting points; DESIGN.md section 4, "The look-ahead form").  Same results as the plain form
+ * up to float rounding.  Process-wide, read when a schedule is created (like cu2rec_blocksolve_min_rate); 0 = off (default);
+ * CU2REC_BLOCKSOLVE_LOOKAHEAD in the environment sets the initial value.  Returns the previous value; blocks < 0 only queries. */
+int cu2rec_blocksolve_lookahead_blocks(int blocks);
 /* Development aid: while `buffer` (device memory, 8 * (1 + 8 * capacity) bytes, zeroed by the caller) is set, every
  * wavefront of the block-solve kernels writes {kernel, id, start, end, 4 marks (trace builds)} in ticks of the 100 MHz device clock into record
- * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 5 walk; records never written stay
+ * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 5 walk, 6 affine builder, 7 cross blocks; records never written stay
  * zero).  NULL switches it off. */
 int cu2rec_debug_blocksolve_stamps(void *buffer, int capacity);
 

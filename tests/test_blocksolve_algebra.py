@@ -188,3 +188,96 @@ def test_affine_chain_f32_rounding_gap_is_small():
     got = affine_chain(P, ub, r, q, b, 3.5, 0.01, regs, 64, np.float32)
     for g, w in zip(got, want):
         assert np.abs(np.asarray(g, np.float64) - np.asarray(w, np.float64)).max() < 2e-5
+
+
+def lookahead_chain(P, ub, r, q, b, gb, lr, regs, dtype):
+    """The look-ahead form of the chain (bs_chain_kernel, round 4).  Blocks of B = 64 links; block i >= 1 takes its
+    right-hand side from the state in front of block i - 1 and the errors of block i - 1:
+        e_i   = M_i (pre_i - N_i e_(i-1)),   pre_i[k] = base_i[k] - c^(k+64) b_(i-1) - a^(k+64) (p_(i,k) . q_(i-1))
+        N_i[k][j] = lr (c^(63+k-j) + a^(63+k-j) (p_(i,k) . p_(i-1,j)))            -- the block of lr L below the diagonal block
+    (M_i = (I + N_ii)^-1 as before; block 0 as in blocked_chain).  N_i is a cross Gram matrix of two neighbouring blocks' rows --
+    no chain state in it, phase 1 builds it -- so the only dependent work per block is two 64 x 64 mat-vecs; the state
+    (q_i, b_i) follows the errors one block behind (q_(i+1) = a^n q_i + lr sum_j a^(n-1-j) e_i[j] p_(i,j)) and is needed
+    again only for pre_(i+2)."""
+    B = 64
+    p_reg, q_reg, ub_reg, ib_reg = (dtype(v) for v in regs)
+    lr = dtype(lr)
+    a, c = 1.0 - float(lr) * float(q_reg), 1.0 - float(lr) * float(ib_reg)
+    ap, au = dtype(1.0 - float(lr) * float(p_reg)), dtype(1.0 - float(lr) * float(ub_reg))
+    P0, ub0 = P.astype(dtype), ub.astype(dtype)
+    apow = (a ** np.arange(2 * B + 1)).astype(dtype)
+    cpow = (c ** np.arange(2 * B + 1)).astype(dtype)
+    adel = (1.0 - a ** np.arange(2 * B + 1)).astype(dtype)
+    cdel = (1.0 - c ** np.arange(2 * B + 1)).astype(dtype)
+    nblk = (len(r) + B - 1) // B
+    qs, bs = [q.astype(dtype).copy()], [dtype(b)]  # state in front of every block
+    errs = np.zeros(len(r), dtype)
+    e_prev = None
+    for i in range(nblk):
+        m0 = i * B
+        Pm, n = P0[m0:m0 + B], min(B, len(r) - m0)
+        kk = np.arange(n)
+        k, j = np.meshgrid(kk, kk, indexing="ij")
+        low = j < k
+        d = np.where(low, k - 1 - j, 0)
+        G = (Pm @ Pm.T).astype(dtype)
+        Nd = np.where(low, lr * (cpow[d] + apow[d] * G), dtype(0)).astype(dtype)
+        M = np.linalg.inv((np.eye(n) + Nd).astype(np.float64)).astype(dtype)
+        base = (r[m0:m0 + n].astype(dtype) - dtype(gb)) - ub0[m0:m0 + n]
+        if i == 0:
+            dots = (Pm @ qs[0]).astype(dtype)
+            t = ((base - (bs[0] - cdel[kk] * bs[0])) - (dots - adel[kk] * dots)).astype(dtype)
+        else:
+            Pp = P0[m0 - B:m0]
+            X = (Pm @ Pp.T).astype(dtype)
+            kx, jx = np.meshgrid(kk, np.arange(B), indexing="ij")
+            dx = B - 1 + kx - jx
+            N = (lr * (cpow[dx] + apow[dx] * X)).astype(dtype)
+            g = (Pm @ qs[i - 1]).astype(dtype)
+            pre = ((base - (bs[i - 1] - cdel[kk + B] * bs[i - 1])) - (g - adel[kk + B] * g)).astype(dtype)
+            t = (pre - N @ e_prev).astype(dtype)
+        e = (M @ t).astype(dtype)
+        errs[m0:m0 + n] = e
+        w = (lr * apow[n - 1 - kk] * e).astype(dtype)
+        qs.append(((qs[i] - adel[n] * qs[i]) + w @ Pm).astype(dtype))
+        bs.append((bs[i] - cdel[n] * bs[i]) + np.sum(lr * cpow[n - 1 - kk] * e, dtype=dtype))
+        e_prev = e
+    # the user side as in blocked_chain (phase 3), from the start states and the errors
+    P_new, ub_new = np.empty_like(P0), np.empty_like(ub0)
+    for i in range(nblk):
+        m0 = i * B
+        Pm, n = P0[m0:m0 + B], min(B, len(r) - m0)
+        kk = np.arange(n)
+        k, j = np.meshgrid(kk, kk, indexing="ij")
+        low = j < k
+        d = np.where(low, k - 1 - j, 0)
+        e = errs[m0:m0 + n]
+        T = np.where(low, lr * apow[d] * e[None, :], dtype(0)).astype(dtype)
+        Qh = ((qs[i][None, :] - adel[:n, None] * qs[i][None, :]) + T @ Pm).astype(dtype)
+        P_new[m0:m0 + n] = ap * Pm + lr * e[:, None] * Qh
+        ub_new[m0:m0 + n] = au * ub0[m0:m0 + n] + lr * e
+    return P_new, ub_new, qs[-1], bs[-1], errs
+
+
+@pytest.mark.parametrize("n,f", [(1, 8), (64, 10), (65, 10), (127, 100), (200, 100), (1979, 100), (450, 112)])
+def test_lookahead_chain_equals_sequential_f64(n, f):
+    rng = np.random.default_rng(n * 1000 + f + 2)
+    P, q = rng.normal(0, 0.3, (n, f)), rng.normal(0, 0.3, f)
+    ub, b, r = rng.normal(0, 0.3, n), 0.2, rng.integers(1, 11, n) / 2.0
+    regs = (0.02, 0.03, 0.04, 0.05)
+    want = sequential_chain(P, ub, r, q, b, 3.5, 0.01, regs, np.float64)
+    got = lookahead_chain(P, ub, r, q, b, 3.5, 0.01, regs, np.float64)
+    for g, w in zip(got, want):
+        assert np.allclose(g, w, rtol=0, atol=1e-11), np.abs(np.asarray(g) - np.asarray(w)).max()
+
+
+def test_lookahead_chain_f32_rounding_gap_is_small():
+    rng = np.random.default_rng(9)
+    n, f = 1979, 100
+    P, q = rng.normal(0, 0.3, (n, f)), rng.normal(0, 0.3, f)
+    ub, b, r = rng.normal(0, 0.3, n), 0.2, rng.integers(1, 11, n) / 2.0
+    regs = (0.02, 0.02, 0.02, 0.02)
+    want = sequential_chain(P, ub, r, q, b, 3.5, 0.01, regs, np.float32)
+    got = lookahead_chain(P, ub, r, q, b, 3.5, 0.01, regs, np.float32)
+    for g, w in zip(got, want):
+        assert np.abs(np.asarray(g, np.float64) - np.asarray(w, np.float64)).max() < 2e-5

@@ -84,6 +84,30 @@ def test_blocksolve_affine_form_matches_sequential_oracle(min_rate, users, items
         cu.api.blocksolve_affine_head(prev_head)
 
 
+@pytest.mark.parametrize("users,items,nnz,f,iters,rate,la", [
+    (300, 120, 6000, 10, 70, 2.0, 1),       # every chain of two blocks and more; crosses a schedule batch
+    (3000, 40, 30000, 100, 6, 1.0, 1),      # three blocks a chain, the last one partial
+    (9000, 6, 40000, 100, 3, 1.0, 10),      # ~24 blocks a chain: the rings go round many times
+    (9000, 6, 40000, 116, 3, 1.0, 2),       # the widest row the form takes (29 slots)
+    (2000, 300, 40000, 128, 5, 0.5, 1),     # wider: stays in the plain form
+    (9000, 12, 60000, 40, 4, 1.0, 8),       # mixed: chains on both sides of the threshold
+    (9000, 3, 30000, 1, 3, 1.0, 1),         # f = 1, ~47 blocks a chain
+    (9000, 6, 40000, 64, 3, 1.0, 3),        # 16 slots: the narrow instantiation's last bucket
+    (20000, 300, 90000, 16, 3, 8.0, 1),     # ~280 hot chains, most of them two or three blocks
+])
+def test_blocksolve_lookahead_form_matches_sequential_oracle(min_rate, users, items, nnz, f, iters, rate, la):
+    """cu2rec_blocksolve_lookahead_blocks: the leading chains run phase 2 as e_i = M_i (pre_i - N_i e_(i-1)) on one wavefront,
+    the item row one block behind (blocksolve.hip, chain_lookahead); the formulas: tests/test_blocksolve_algebra.py."""
+    min_rate(rate)
+    prev = cu.api.blocksolve_lookahead_blocks(la)
+    try:
+        tr, _ = synth.make_ratings(users, items, nnz, min_degree=3, seed=users + f)
+        model, state = _run_both(tr, f, iters)  # (the schedule is created here: it reads the setting)
+        assert max(_max_diffs(model, state)) <= 2e-6
+    finally:
+        cu.api.blocksolve_lookahead_blocks(prev)
+
+
 def test_blocksolve_without_hot_items_is_the_ordered_walk_bit_for_bit(min_rate):
     min_rate(1e9)
     tr, _ = synth.make_ratings(3000, 40, 30000, min_degree=3, seed=11)
@@ -189,6 +213,32 @@ def test_blocksolve_affine_form_full_shape_ml20m_against_the_ordered_mode():
     diffs = [float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(model.download(), want)]
     assert max(diffs) <= 5e-6, diffs
     assert any(not np.array_equal(g, w) for g, w in zip(model.download(), plain.download())), "the affine form did not run"
+
+
+def test_blocksolve_lookahead_form_full_shape_ml20m_against_the_ordered_mode():
+    """The opt-in look-ahead form at the ML-20M shape, f=100: items expected to collect 12 blocks and more per iteration (the
+    chains that ARE phase 2's duration).  72 iterations (a schedule batch is crossed) against the ordered mode -- the sequential
+    result bit for bit -- on the same sample stream: every parameter within 5e-6, and not the plain block-solve bits."""
+    import bench
+    tr, _ = bench.load_dataset("ml-20m", 20240917, 0, lambda: None)
+    f, iters = 100, 72
+    d_tr = cu.DeviceCSR(tr)
+    exact = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    exact.sgd(d_tr, HYPER, 42, 0, iters, mode="ordered")
+    plain = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    plain.sgd(d_tr, HYPER, 42, 0, iters, mode="blocksolve")
+    prev = cu.api.blocksolve_lookahead_blocks(12)
+    try:
+        d_la = cu.DeviceCSR(tr)  # the setting is read when the schedule is created
+        assert d_la.blocksolve_items() > 0
+        model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+        model.sgd(d_la, HYPER, 42, 0, iters, mode="blocksolve")
+    finally:
+        cu.api.blocksolve_lookahead_blocks(prev)
+    want = exact.download()
+    diffs = [float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(model.download(), want)]
+    assert max(diffs) <= 5e-6, diffs
+    assert any(not np.array_equal(g, w) for g, w in zip(model.download(), plain.download())), "the look-ahead form did not run"
 
 
 def test_blocksolve_full_shape_netflix_f128_against_the_cpu_oracle():

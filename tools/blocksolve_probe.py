@@ -79,7 +79,7 @@ def main():
             print("xcc of", nm, "records (id -> xcc):", [(int(i), int(x)) for i, x in zip(rec[sel, 1][:24], xcc[sel][:24])])
         n = len(rec)
         t_min = rec[:, 2].min()
-        names = {1: "gram", 2: "solver", 3: "loader", 4: "update", 5: "walk", 6: "build"}
+        names = {1: "gram", 2: "solver", 3: "loader", 4: "update", 5: "walk", 6: "build", 7: "cross"}
         print("stamps: %d wavefront records; times in us from the first start" % n)
         for kid in sorted(names):
             r = rec[rec[:, 0] == kid]
@@ -95,7 +95,7 @@ def main():
                 mk = (rr[:, 4:] - rr[:, 2:3]) / 100.0
                 print("   marks after start (mean us over %d waves):" % len(rr), [round(float(v), 2) for v in mk.mean(axis=0)])
                 if kid in (2, 3):
-                    for row in list(rr[:4]) + list(rr[-6:]):
+                    for row in list(rr[:8]) + list(rr[-4:]):
                         print("     chain %d wave %d:" % (row[1] // 4, row[1] % 4), [round(float(v - row[2]) / 100.0, 2) for v in row[4:]], "end", round(float(row[3] - row[2]) / 100.0, 2))
             if kid in (3, 4):
                 cyc = (r[:, 7] - r[:, 2]).astype(np.float64)
