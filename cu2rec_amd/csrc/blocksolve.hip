@@ -30,6 +30,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -96,7 +97,7 @@ __device__ __forceinline__ void acquire_agent_now() {  // L1 invalidate, complet
 __device__ __forceinline__ void store_through(float *p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v));
 }
-constexpr unsigned long long kSpinTimeoutTicks = 200000000ull;  // 2 s of the 100 MHz wall clock: every wait in here is bounded
+// every device-side wait in here is bounded: BsIteration::wait_ticks (bs_wait_ticks(): CU2REC_BS_WAIT_S seconds, default 2) of the 100 MHz wall clock
 
 // v[l] + v[l ^ 16] in every lane
 __device__ __forceinline__ float row_pair_sum(float v) {
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
             unsigned polls = 0;
             while (ld_agent(it.solve_started) < it.started_target) {
                 __builtin_amdgcn_s_sleep(16);
-                if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+                if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
                     __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -600,7 +601,7 @@ __device__ __forceinline__ int await_blocks(const BsIteration &it, int g0, int n
         ready += mask == ~0ull ? 64 : __ffsll(static_cast<unsigned long long>(~mask)) - 1;  // leading announced blocks
         if (ready >= need) break;
         __builtin_amdgcn_s_sleep(8);
-        if ((++polls & 31u) == 0 && (ld_agent_now(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+        if ((++polls & 31u) == 0 && (ld_agent_now(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
             if (lane == 0) st_agent_u32(it.status, 1u);
             ready = nblk;
             break;
@@ -868,7 +869,7 @@ __device__ __forceinline__ void bs_affine_chain(const SgdArgs &a, const BsIterat
         unsigned polls = 0;
         while (ld_agent(it.aff_flag + g0 + m) != it.epoch) {
             __builtin_amdgcn_s_sleep(8);
-            if ((++polls & 63u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+            if ((++polls & 63u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
                 __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -924,7 +925,7 @@ __device__ __forceinline__ void bs_affine_chain(const SgdArgs &a, const BsIterat
         unsigned long long v;
         while (static_cast<unsigned>((v = ld_agent(gr)) >> 32) != it.epoch) {
             __builtin_amdgcn_s_sleep(2);
-            if ((++polls & 255u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+            if ((++polls & 255u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
                 __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -1373,7 +1374,7 @@ __device__ __forceinline__ void la_wait(unsigned *sy, int word, unsigned target,
         __builtin_amdgcn_s_sleep(1);
         if ((++polls & 1023u) == 0) {
             if (t0 == 0) t0 = wall_clock64();
-            if (__hip_atomic_load(sy + kSyAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks) {
+            if (__hip_atomic_load(sy + kSyAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || wall_clock64() - t0 > it.wait_ticks) {
                 __hip_atomic_store(sy + kSyAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if ((threadIdx.x & 63) == 0) __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -1406,7 +1407,7 @@ __device__ __forceinline__ void la_wait4(unsigned *sy, int word, unsigned target
         __builtin_amdgcn_s_sleep(1);
         if ((++polls & 1023u) == 0) {
             if (t0 == 0) t0 = wall_clock64();
-            if (__hip_atomic_load(sy + kSyAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks) {
+            if (__hip_atomic_load(sy + kSyAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || wall_clock64() - t0 > it.wait_ticks) {
                 __hip_atomic_store(sy + kSyAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if ((threadIdx.x & 63) == 0) __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -1433,7 +1434,7 @@ __device__ __forceinline__ void la_wait2(unsigned *sy, int word, unsigned target
         __builtin_amdgcn_s_sleep(1);
         if ((++polls & 1023u) == 0) {
             if (t0 == 0) t0 = wall_clock64();
-            if (__hip_atomic_load(sy + kSyAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks) {
+            if (__hip_atomic_load(sy + kSyAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || wall_clock64() - t0 > it.wait_ticks) {
                 __hip_atomic_store(sy + kSyAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if ((threadIdx.x & 63) == 0) __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -1858,9 +1859,11 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
         if (threadIdx.x == 0) {
             const unsigned long long t0 = wall_clock64();
             unsigned polls = 0;
+            // (this wait guards DATA -- the next phase 1 reads rows the side kernel writes -- so it gives up only when the GPU must be
+            // taken for wedged: 15 x the bound of the other waits, 30 s by default; then the status word is set and the call reports it)
             while (ld_agent(it.side_seq) < it.side_target) {
                 __builtin_amdgcn_s_sleep(16);
-                if ((++polls & 63u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+                if ((++polls & 63u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > 15ull * it.wait_ticks)) {
                     __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -1895,7 +1898,7 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
             const unsigned long long v = ld_agent(progress);
             if ((v >> 32) == it.epoch && v >= want) break;
             __builtin_amdgcn_s_sleep(48);  // ~1.3 us: hundreds of workgroups poll a few dozen words
-            if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
+            if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
                 __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
@@ -2100,6 +2103,15 @@ void bs_check_fault() {
     }
 }
 
+unsigned long long bs_wait_ticks() {  // CU2REC_BS_WAIT_S (seconds, default 2): the bound of the device-side waits, in ticks of the 100 MHz clock
+    static const unsigned long long ticks = [] {
+        double sec = 2.0;
+        if (const char *env = std::getenv("CU2REC_BS_WAIT_S")) sec = std::max(0.001, std::atof(env));
+        return static_cast<unsigned long long>(sec * 1e8);
+    }();
+    return ticks;
+}
+
 bool bs_supported(int nslots) { return nslots >= 1 && nslots <= kBsMaxSlots; }
 bool bs_lookahead_supported(int nslots) { return la_supported(nslots); }
 
@@ -2141,8 +2153,10 @@ void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream,
 }
 
 namespace {
+// A gate that gives up just ENDS (the side kernel then starts a little early: a matter of timing, no data hangs on it): it must not
+// set the status word -- that would declare the model state undefined for a delay that harms nothing.
 __global__ void bs_gate_kernel(const unsigned long long *count, unsigned long long target, const unsigned long long *started,
-                               unsigned long long started_target, unsigned *status) {
+                               unsigned long long started_target, unsigned long long wait_ticks) {
     // lanes 0-31: one shard of phase 1's count each; lane 32: phase 2's workgroups that hold their CU
     const int lane = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
@@ -2155,10 +2169,7 @@ __global__ void bs_gate_kernel(const unsigned long long *count, unsigned long lo
         const unsigned long long st = ld_agent(started);
         if (sum >= target && st >= started_target) break;
         __builtin_amdgcn_s_sleep(16);
-        if ((++polls & 63u) == 0 && (ld_agent(status) != 0u || wall_clock64() - t0 > kSpinTimeoutTicks)) {
-            if (lane == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
+        if ((++polls & 63u) == 0 && wall_clock64() - t0 > wait_ticks) break;
     }
 }
 }  // namespace
@@ -2176,7 +2187,7 @@ void bs_launch_signal(unsigned long long *word, unsigned long long value, hipStr
 
 void bs_launch_gate(const unsigned long long *count, unsigned long long target, const unsigned long long *started,
                     unsigned long long started_target, hipStream_t stream) {
-    hipLaunchKernelGGL(bs_gate_kernel, dim3(1), dim3(64), 0, stream, count, target, started, started_target, bs_status_word());
+    hipLaunchKernelGGL(bs_gate_kernel, dim3(1), dim3(64), 0, stream, count, target, started, started_target, bs_wait_ticks());
     CU2REC_HIP(hipGetLastError());
 }
 

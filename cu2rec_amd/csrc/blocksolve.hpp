@@ -88,15 +88,18 @@ struct BsIteration {
     unsigned long long started_target;   //      ... including all of this iteration's
     // development aid (cu2rec_debug_blocksolve_stamps): [0] = entries appended so far, then {kernel, id, start, end}
     // per wavefront in units of the 100 MHz s_memrealtime clock; nullptr in normal operation
+    unsigned long long wait_ticks;    // bound of the device-side waits (bs_wait_ticks(): CU2REC_BS_WAIT_S, 2 s), 100 MHz ticks
     unsigned long long *stamps;
     int stamps_cap;
     int dbg;  // CU2REC_BS_DBG, timing experiments only (results undefined): 1 plain stores in phase 1, 2 phase 1 does not wait for
-              // phase 2's start, 4 phase 2 does not wait for records, 8 phase 3 does not wait for progress
+              // phase 2's start, 4 phase 2 does not wait for records, 8 phase 3 does not wait for progress; fault-path tests
+              // (tests/test_gpu_blocksolve.py): 16 the side stream's signal is never sent, 32 the side stream's gate can never open
 };
 
 // process-wide stamp buffer for the launches that follow (nullptr = off)
 void bs_set_stamps(unsigned long long *buf, int cap);
 void bs_get_stamps(unsigned long long **buf, int *cap);
+unsigned long long bs_wait_ticks();
 bool bs_supported(int nslots);
 bool bs_lookahead_supported(int nslots);  // rows of at most 31 float4 slots: the look-ahead form's rings fit the LDS
 int bs_compute_units();       // of the current device

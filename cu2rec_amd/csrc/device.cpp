@@ -48,8 +48,16 @@ struct PartialSums {
 // the reference copies every block's partial sum back and adds them on the host, twice per metric pair (loss.cu:183-190), and
 // so did rounds 1-2 here (64 KB through a pageable staging copy).
 PartialSums collect_partials(double *device_partials, int blocks, hipStream_t stream) {
-    thread_local double *pinned = nullptr;
-    if (!pinned) CU2REC_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), 2 * sizeof(double), hipHostMallocDefault));
+    // two doubles of pinned memory per host thread, released with the thread (the runtime may be gone by then: errors ignored)
+    struct Pinned {
+        double *p = nullptr;
+        ~Pinned() {
+            if (p) (void)hipHostFree(p);
+        }
+    };
+    thread_local Pinned holder;
+    if (!holder.p) CU2REC_HIP(hipHostMalloc(reinterpret_cast<void **>(&holder.p), 2 * sizeof(double), hipHostMallocDefault));
+    double *pinned = holder.p;
     launch_partials_reduce(device_partials, blocks, stream);
     CU2REC_HIP(hipGetLastError());
     CU2REC_HIP(hipMemcpyAsync(pinned, device_partials + 2 * kMaxPartialBlocks, 2 * sizeof(double), hipMemcpyDeviceToHost, stream));

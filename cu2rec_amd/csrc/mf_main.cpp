@@ -65,7 +65,9 @@ void read_all(int fd, void *buf, size_t n) {
 int run_rank(int rank, int nranks, int mode, int sync_every, int merge, const std::string &config_path,
              const std::string &train_path, const std::string &test_path, const std::vector<int> &to_child,
              const std::vector<int> &from_child, int up, int down) {
-    // fault injection for the failure-propagation test (tests/test_host_abi.py), before anything touches a GPU:
+#ifdef CU2REC_TEST_HOOKS
+    // fault injection for the failure-propagation test (tests/test_host_abi.py), before anything touches a GPU -- compiled into
+    // the test binary build/test/mf_hooks only (make -C cu2rec_amd/csrc test-hooks), never into bin/mf:
     // CU2REC_TEST_RANK_EXIT="r:code" makes rank r end with that exit code, CU2REC_TEST_RANK_HANG="r" makes rank r sit still
     // the way a rank inside a collective whose peer died would
     if (const char *env = std::getenv("CU2REC_TEST_RANK_EXIT")) {
@@ -74,6 +76,7 @@ int run_rank(int rank, int nranks, int mode, int sync_every, int merge, const st
     }
     if (const char *env = std::getenv("CU2REC_TEST_RANK_HANG"))
         if (std::atoi(env) == rank) std::this_thread::sleep_for(std::chrono::seconds(120));
+#endif
     if (cu2rec_device_count() < nranks) throw std::runtime_error("fewer HIP devices than ranks (-g)");
     cu2rec::check(cu2rec_set_device(rank));
     if (rank == 0) {
@@ -231,6 +234,8 @@ int run_multi_gpu(int nranks, int mode, int sync_every, int merge, const std::st
                 kill_children();
                 for (int q = 1; q < nranks; ++q)
                     if (!reaped[q].load()) (void)waitpid(pids[q], &status, 0);  // SIGKILL: at once
+                std::fflush(stdout);  // the TRAIN: / TEST: lines rank 0 has printed so far are not lost with the process
+                std::fflush(stderr);
                 _exit(3);  // rank 0 (this process) may be inside a collective that will never complete
             }
             std::this_thread::sleep_for(std::chrono::milliseconds(20));

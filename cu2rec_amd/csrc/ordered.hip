@@ -1157,6 +1157,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.gram_done = nullptr;
                 it.side_seq = nullptr;
                 it.side_target = 0;
+                it.wait_ticks = bs_wait_ticks();
                 bs_get_stamps(&it.stamps, &it.stamps_cap);
                 static const int dbg = std::getenv("CU2REC_BS_DBG") ? std::atoi(std::getenv("CU2REC_BS_DBG")) : 0;  // timing experiments
                 it.dbg = dbg;
@@ -1178,18 +1179,23 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                         // of the side kernel (after phase 1 in host order: streams sharing a hardware queue serialise, they cannot
                         // wait for each other) ends when the whole grid is through.  Phase 1 is a plain launch then: phase 2 starts
                         // right behind it (an event riding on its completion signal costs 5 us before phase 2).
+                        // (the host's counts move only behind a launch that succeeded: a launch that throws leaves gate and counters
+                        // in step for the calls that follow)
                         it.gram_done = gram_done.ptr;
-                        gram_done_target += static_cast<unsigned long long>(max_blocks + it.la_grid);
-                        started_total += static_cast<unsigned long long>(n_hot_bs);
                         bs_launch_gram(a, it, stream);
+                        gram_done_target += static_cast<unsigned long long>(max_blocks + it.la_grid);
                     } else {
                         bs_launch_gram(a, it, stream, markers ? nullptr : ev_gram);
                         if (markers) CU2REC_HIP(hipEventRecord(ev_gram, stream));
                         CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
                     }
                     bs_launch_solve(a, it, stream);
+                    if (it.gram_done) started_total += static_cast<unsigned long long>(n_hot_bs);  // (counted by its workgroups only then)
                     // (the gate behind phase 2 in host order: it also waits for phase 2's workgroups to hold their CUs)
-                    if (it.gram_done) bs_launch_gate(gram_done.ptr, gram_done_target, solve_started.ptr, started_total, upd);
+                    // (CU2REC_BS_DBG & 32, fault-path test: a gate that can never be satisfied -- it gives up after the bound and the run
+                    // goes on, results unchanged)
+                    if (it.gram_done)
+                        bs_launch_gate(gram_done.ptr, gram_done_target + ((dbg & 32) ? (1ull << 40) : 0ull), solve_started.ptr, started_total, upd);
                     launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(b) << item_bits,
                                   std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, kRoleDuo | kRoleWalk,
                                   chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1), markers ? nullptr : ev_upd);
@@ -1197,7 +1203,10 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                     if (device_join) {
                         // a signal kernel behind the side kernel, and one more workgroup in phase 3 that waits for it (queued BEHIND
                         // the signal in host order): the next phase 1 follows phase 3 without an event
-                        bs_launch_signal(side_seq.ptr, ++side_seq_host, upd);
+                        // (CU2REC_BS_DBG & 16, fault-path test: the signal is never sent -- phase 3's waiting workgroup gives up after
+                        // 15 x the bound, the status word is set and the next entry point returns CU2REC_EHIP)
+                        ++side_seq_host;
+                        if (!(dbg & 16)) bs_launch_signal(side_seq.ptr, side_seq_host, upd);
                         it.side_seq = side_seq.ptr;
                         it.side_target = side_seq_host;
                     }

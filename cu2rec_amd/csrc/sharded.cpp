@@ -330,6 +330,10 @@ void ShardJob::run(const cu2rec_hyper &h, uint64_t seed, uint64_t iter0, int n_i
 void ShardJob::loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq, double *n_total, float *mae, float *rmse,
                     hipStream_t stream) {
     double host[3] = {0.0, 0.0, static_cast<double>(ratings.nnz)};
+    // the wire all-reduce of an exchange may still be queued on `stream`, and the loss pass ends in a plain
+    // hipStreamSynchronize: wait for it HERE, bounded (Comm::wait polls ncclCommGetAsyncError and gives up after
+    // CU2REC_COMM_TIMEOUT_S), or a dead peer would hold this rank inside that synchronize for ever
+    if (comm.nranks > 1) comm.wait(stream);
     model.loss(ratings, &host[0], &host[1], nullptr, nullptr, stream);
     if (comm.nranks > 1) {
         CU2REC_HIP(hipMemcpyAsync(sums.ptr, host, sizeof(host), hipMemcpyHostToDevice, stream));

@@ -133,11 +133,14 @@ def shard_of(train, test, rank, nranks):
     return u0, u1, train.slice_users(u0, u1), test.slice_users(u0, u1)
 
 
-def train_sharded(comm, train, test, cfg, mode=api.SGD_BLOCKSOLVE, sync_every=0, merge="adaptive", verbose=True):
+def train_sharded(comm, train, test, cfg, mode=None, sync_every=0, merge="adaptive", verbose=True):
     """train() (training.h:12-15) over all ranks through the C++ driver.  train / test: the FULL HostCSR on every rank.
+    mode None = api.default_mode(cfg.n_factors), as api.train, bin/mf and mf_mgpu (block-solve; `ordered` above 252 factors).
     Returns (P_local, Q, losses, user_bias_local, item_bias, (u0, u1), stats)."""
     u0, u1, tr, te = shard_of(train, test, comm.rank, comm.nranks)
     f = cfg.n_factors
+    if mode is None:
+        mode = api.default_mode(f)
     # every rank draws the reference's seed-42 initialisation and keeps its slice, so N ranks start exactly where
     # one rank would (training.cu:28,54,212-213)
     P0 = api.initialize_normal_array(train.rows * f, f).reshape(train.rows, f)[u0:u1]

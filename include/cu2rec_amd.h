@@ -310,7 +310,10 @@ int cu2rec_debug_blocksolve_stamps(void *buffer, int capacity);
  * double, MAE = S1/n, RMSE = sqrt(S2/n) returned as float (loss.cu:185-190).
  * errors_out (device, nnz floats) may be NULL; when given it receives the residuals like the
  * reference's error_d array (loss.cu:31).  workspace: device memory of at least
- * cu2rec_loss_workspace_bytes() bytes.  Synchronises `stream` (host results). */
+ * cu2rec_loss_workspace_bytes() bytes.  Synchronises `stream` (host results).
+ * ALWAYS size the workspace by calling cu2rec_loss_workspace_bytes(): it is NOT a constant of the ABI.  It grew by 16 bytes in
+ * round 3 (the per-block partial sums are added on the device and the two results live at the workspace's tail: 2 x 4,096 + 2
+ * doubles); a buffer sized by an older formula would be written past its end. */
 size_t cu2rec_loss_workspace_bytes(void);
 int cu2rec_loss(const int *indptr, const int *indices, const float *data, int n_rows, int nnz,
                 const float *P, int ldp, const float *Q, int ldq, const float *user_bias, const float *item_bias,

@@ -5,6 +5,8 @@ dependent row updates), so it is pinned at a TOLERANCE against the sequential or
   * the north-star bar at BASELINE.json configs[2]'s full shape (ML-20M shape, f=100): after 1,000 iterations
     |test RMSE - oracle| <= 1e-4 and every parameter within 1e-3.
 Where no chain is long enough for a block solve the mode degenerates to the ordered walk and is bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,6 +17,7 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 
 HYPER = (0.01, 0.02, 0.02, 0.02, 0.02)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _as_orc(m):
@@ -366,3 +369,57 @@ def test_blocksolve_random_shapes_long_chains(min_rate, case):
     tr, _ = synth.make_ratings(users, items, users * per_user, min_degree=min(2, per_user), seed=case)
     model, state = _run_both(tr, f, int(rng.randint(2, 5)))
     assert max(_max_diffs(model, state)) <= 3e-6, (f, items, users)
+
+
+_FAULT_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import cu2rec_amd as cu
+from cu2rec_amd import api, synth
+from cu2rec_amd._lib import Cu2recError, check, lib
+from oracle import oracle as orc
+api.blocksolve_min_rate(1.0)
+tr, _ = synth.make_ratings(3000, 40, 30000, min_degree=3, seed=3100)
+f, iters, hyper = 100, 5, (0.01, 0.02, 0.02, 0.02, 0.02)
+d_tr = cu.DeviceCSR(tr)
+assert d_tr.blocksolve_items() > 0
+model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+try:
+    model.sgd(d_tr, hyper, 42, 0, iters, mode="blocksolve")
+    check(lib().cu2rec_check_faults())
+except Cu2recError as e:
+    print("STATUS", e.status, "gave up" in str(e))
+    sys.exit(0)
+state = orc.init_model(tr.rows, tr.cols, f)
+orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias), *state, tr.global_bias, hyper, 42, 0,
+                   iters, dot_order=orc.DOT_TREE16)
+print("OK %%.3e" %% max(float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(model.download(), state)))
+"""
+
+
+def _run_fault_script(dbg):
+    import subprocess
+    import sys
+    env = dict(os.environ, CU2REC_BS_DBG=str(dbg), CU2REC_BS_WAIT_S="0.02")
+    res = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-3000:]
+    return res.stdout.strip().splitlines()[-1]
+
+
+def test_blocksolve_join_wait_that_is_never_satisfied_ends_in_ehip():
+    """The default launch topology's join: phase 3 carries one workgroup that waits for the number a signal kernel behind the side
+    kernel stores.  With the signal never sent (CU2REC_BS_DBG=16) and the waits' bound cut to 20 ms (CU2REC_BS_WAIT_S; the join
+    waits 15 x that) the launch ends by itself, the status word is set and the call reports CU2REC_EHIP -- nothing hangs.  In a
+    process of its own: both settings are read once."""
+    assert _run_fault_script(16) == "STATUS -3 True"
+
+
+def test_blocksolve_gate_that_never_opens_only_costs_time():
+    """The side stream's gate kernel guards timing, not data: one that can never be satisfied (CU2REC_BS_DBG=32) gives up after the
+    bound and the run goes on -- no error, and the result is the oracle's within the mode's usual rounding (a gate
+    timeout must not declare the model state undefined)."""
+    last = _run_fault_script(32)
+    assert last.startswith("OK "), last
+    assert float(last.split()[1]) <= 2e-6, last

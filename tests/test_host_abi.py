@@ -246,12 +246,13 @@ def test_bin_mf_multi_gpu_rank_failure_ends_every_rank(tmp_path):
     """bin/mf -g N (one process per GPU): a rank that dies must not leave the others waiting in a collective for ever.  Rank 1 is
     made to exit with code 7 before it touches anything, rank 0 (the parent) and rank 2 to sit still like ranks inside an
     all-reduce whose peer is gone: the program ends at once, non-zero, and no rank is left behind.  (Fault injection hooks in
-    csrc/mf_main.cpp; no GPU involved.)"""
+    csrc/mf_main.cpp, compiled into the test binary build/test/mf_hooks only -- bin/mf itself ignores the variables; no GPU
+    involved.)"""
     import subprocess
     import time
-    exe = os.path.join(ROOT, "bin", "mf")
+    exe = os.path.join(ROOT, "build", "test", "mf_hooks")
     if not os.path.exists(exe):
-        pytest.skip("bin/mf not built")
+        pytest.skip("build/test/mf_hooks not built (make -C cu2rec_amd/csrc test-hooks)")
     env = dict(os.environ, CU2REC_TEST_RANK_EXIT="1:7", CU2REC_TEST_RANK_HANG="0")
     t0 = time.time()
     res = subprocess.run([exe, "-g", "3", "train.csv", "test.csv"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
@@ -260,7 +261,7 @@ def test_bin_mf_multi_gpu_rank_failure_ends_every_rank(tmp_path):
     assert res.returncode == 3 and "rank 1 ended abnormally (exit code 7)" in res.stderr, (res.returncode, res.stderr)
     # every child is gone (they die with the parent even if it had been killed itself)
     for _ in range(40):
-        out = subprocess.run(["pgrep", "-x", "mf"], stdout=subprocess.PIPE, text=True).stdout.split()
+        out = subprocess.run(["pgrep", "-x", "mf_hooks"], stdout=subprocess.PIPE, text=True).stdout.split()
         if not out:
             break
         time.sleep(0.05)
