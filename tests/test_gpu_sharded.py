@@ -193,20 +193,16 @@ def test_bin_mf_g1_flag_and_sharded_cli_single_rank(tmp_path):
     assert outs[0] == outs[1]
 
 
-def test_eight_shards_adaptive_merge_within_the_stated_tolerance_of_the_sequential_run():
-    """The acceptance tolerance of a user-sharded run (DESIGN.md section 7): after 1,000 iterations of the ML-20M shape, f=100, the
-    test RMSE of N = 8 shards -- block-solve mode per shard, item deltas reconciled once per epoch (115 iterations) with the
-    driver's `adaptive` merge, delta = phi(r_total) / sum_k phi(r_k) * sum_k delta_k, phi(r) = 1 - exp(-6 r) -- stays within
-    6e-4 of the unsharded = sequential result (measured in round 2: +3.9e-4; `weighted`: +1.07e-3, pinned here as the bar the
-    adaptive merge must beat).  Eight ranks emulated on ONE GPU: eight engines run one after the other, the merge arithmetic in
-    torch (the driver's own exchange -- wire pack / ncclAllReduce / apply -- is pinned against the oracle by the two-rank test
-    above; this one pins the CONVERGENCE of the merge rule)."""
+def _emulated_shards_gap(workload, f, iters, sync, n, merges=("adaptive",)):
+    """N user shards emulated on ONE GPU (N engines run one after the other, block-solve mode per shard, the merge arithmetic of the
+    driver's exchange in torch): test RMSE after `iters` iterations minus the unsharded = sequential result, per merge rule.  The
+    driver's own exchange (wire pack / ncclAllReduce / apply) is pinned against the oracle by the two-rank test above; this pins
+    the CONVERGENCE of the merge rule at BASELINE.json configs[3] / [4]'s shapes."""
     import torch
     import bench
     from cu2rec_amd.engine import DeviceRatings, Engine
     from cu2rec_amd.sharded import plan_users
-    train, test = bench.load_dataset("ml-20m", 20240917, 0, lambda: None)
-    f, iters, sync, n = 100, 1000, 115, 8
+    train, test = bench.load_dataset(workload, 20240917, 0, lambda: None)
     dev = torch.device("cuda", 0)
 
     def test_rmse(engines, bounds):
@@ -230,7 +226,7 @@ def test_eight_shards_adaptive_merge_within_the_stated_tolerance_of_the_sequenti
     alpha = torch.tensor(np.where(tot > 0, phi(tot) / np.maximum(phi(rates).sum(0), 1e-300), 1.0), dtype=torch.float32, device=dev)
     weights = torch.tensor(np.where(tot > 0, rates / np.maximum(tot, 1e-300), 1.0 / n), dtype=torch.float32, device=dev)
     got = {}
-    for merge in ("adaptive", "weighted"):
+    for merge in merges:
         engines = [Engine(u1 - u0, train.cols, f, train.global_bias, P=P0[u0:u1], user_bias=ub0[u0:u1], device=dev) for u0, u1 in bounds]
         d = [DeviceRatings(s, dev) for s in shards]
         Qb, ibb = engines[0].Q.clone(), engines[0].item_bias.clone()
@@ -253,5 +249,58 @@ def test_eight_shards_adaptive_merge_within_the_stated_tolerance_of_the_sequenti
                 e.item_bias.copy_(ibb)
         got[merge] = test_rmse(engines, bounds) - ref
         del engines, d
+    return got
+
+
+def test_eight_shards_adaptive_merge_within_the_stated_tolerance_of_the_sequential_run():
+    """The acceptance tolerance of a user-sharded run (DESIGN.md section 7): after 1,000 iterations of the ML-20M shape, f=100, the
+    test RMSE of N = 8 shards -- block-solve mode per shard, item deltas reconciled once per epoch (115 iterations) with the
+    driver's `adaptive` merge, delta = phi(r_total) / sum_k phi(r_k) * sum_k delta_k, phi(r) = 1 - exp(-6 r) -- stays within
+    6e-4 of the unsharded = sequential result (measured in round 2: +3.9e-4; `weighted`: +1.07e-3, pinned here as the bar the
+    adaptive merge must beat)."""
+    got = _emulated_shards_gap("ml-20m", 100, 1000, 115, 8, ("adaptive", "weighted"))
     assert abs(got["adaptive"]) <= 6e-4, got
     assert abs(got["adaptive"]) < abs(got["weighted"]), got
+
+
+def test_two_shards_adaptive_merge_meets_the_1e4_bar():
+    """BASELINE.json configs[3] at N = 2 (emulated): the sharded run's test RMSE after 1,000 iterations stays within the north
+    star's 1e-4 of the sequential result (measured: -1e-5)."""
+    got = _emulated_shards_gap("ml-20m", 100, 1000, 115, 2)
+    assert abs(got["adaptive"]) <= 1e-4, got
+
+
+def test_four_shards_adaptive_merge_is_outside_the_1e4_bar_by_this_much():
+    """BASELINE.json configs[3] at N = 4 (emulated): measured +1.7e-4 -- OUTSIDE the north star's 1e-4 (a sharded run reconciles the
+    item side once per epoch; it is not the sequential run), inside the stated tolerance of 3e-4 for N = 4.  No merge rule tried
+    brings N >= 4 under 1e-4 (exchanging more often does not help, the bias is in the merge)."""
+    got = _emulated_shards_gap("ml-20m", 100, 1000, 115, 4)
+    assert abs(got["adaptive"]) <= 3e-4, got
+
+
+def test_eight_shards_netflix_f128_within_the_stated_tolerance():
+    """BASELINE.json configs[4] (Netflix shape, f=128, 8 shards, emulated): 660 iterations, exchange every 165 (one epoch): the
+    sharded run's test RMSE sits 1.2e-3 BELOW the sequential run's at that point of the trajectory (nearly every one of the 17,770
+    items is updated many times per iteration by every shard: the adaptive merge is the mean there).  Pinned: |gap| <= 1.6e-3, and
+    the sign."""
+    got = _emulated_shards_gap("netflix", 128, 660, 165, 8)
+    assert -1.6e-3 <= got["adaptive"] <= 0.0, got
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it: the program starts its two ranks itself (torch.distributed.run, fresh
+    processes; here sharing the one GPU through gloo) and rank 0's JSON line says n_gpus 2."""
+    import json
+    import subprocess
+    env = dict(os.environ, CU2REC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "ml-1m",
+                          "--factors", "50", "--no-cpu-baseline", "--no-side-modes"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0
+    assert line["config"]["sharded_run_tolerance"] is not None
