@@ -223,8 +223,23 @@ float orc_uniform(uint32_t x) {
     return inv + (float)x * inv;
 }
 
+/* Tier 3 of the parity protocol only (tests/test_oracle_golden.py): the reference CPU twin draws std::uniform_int_distribution(low, high)
+ * -- INCLUSIVE of high (mf_sequential.cu:111), so with probability 1 / (n + 1) a user trains on the NEXT user's first rating (the
+ * last user: one past the array, clamped here).  Never on in the product's parity tests: the half-open range of sgd.cu:37 is the
+ * sampler everywhere else. */
+static int g_inclusive_range = 0;
+static int g_sample_limit = 0;
+void orc_set_inclusive_range(int on, int nnz) {
+    g_inclusive_range = on;
+    g_sample_limit = nnz;
+}
+
 int orc_sample(uint64_t seed, uint64_t user, uint64_t iteration, int low, int high) {
     float u = orc_uniform(orc_draw(seed, user, iteration));
+    if (g_inclusive_range) {
+        int y = (int)ceilf(u * (float)(high - low + 1)) - 1 + low; /* mf_sequential.cu:111 */
+        return y < g_sample_limit ? y : g_sample_limit - 1;
+    }
     return (int)ceilf(u * (float)(high - low)) - 1 + low; /* sgd.cu:37 */
 }
 

@@ -175,6 +175,31 @@ def main():
                    "ML_SMALL": "the reference's bundled ratings_mapped.csv (610 x 9724, 100836 ratings); not shipped",
                    "cases": cases}, fh, indent=1)
 
+    # ---- Tier 3: the UNMODIFIED reference binary's own run-to-run band.  Its sampler draws from a fresh
+    # std::random_device per update (mf_sequential.cu:109-112: no seed reaches it; inclusive range), so identical runs differ;
+    # the oracle's trajectory (counter-based sampler, half-open range) must lie inside that band, statistically
+    # (tests/test_oracle_golden.py::test_oracle_trajectory_lies_in_the_unmodified_reference_band).
+    if have_ml:
+        fields = [0, 500, 10, 0.01, 42, 0.02, 0.02, 0.02, 0.02]
+        runs = [run_ref(mf_cpu, fields, REF_ML_SMALL, REF_ML_SMALL) for _ in range(TIER3_RUNS)]
+        band = {}
+        for it in (1, 500):
+            vals = {"rmse": [], "mae": []}
+            for lines in runs:
+                for l in lines:
+                    if l["split"] == "TRAIN" and l["iteration"] == it:
+                        vals["rmse"].append(float(l["rmse"]))
+                        vals["mae"].append(float(l["mae"]))
+            assert len(vals["rmse"]) == TIER3_RUNS, (it, vals)
+            band[str(it)] = {k: {"min": min(v), "max": max(v), "runs": v} for k, v in vals.items()}
+            print("tier 3 band, iteration", it, band[str(it)]["rmse"]["min"], band[str(it)]["rmse"]["max"])
+        with open(os.path.join(GOLD, "ref_tier3_band.json"), "w") as fh:
+            json.dump({"generator": "oracle/gen_golden.py", "binary": "oracle/_ref/mf_cpu (unmodified reference)",
+                       "train": "ML_SMALL", "test": "ML_SMALL", "cfg": fields, "runs": TIER3_RUNS, "band": band}, fh, indent=1)
+
+
+TIER3_RUNS = 8
+
 
 if __name__ == "__main__":
     main()

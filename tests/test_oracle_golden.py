@@ -169,6 +169,55 @@ def test_sgd_bit_exact_vs_reference(idx):
         assert hashlib.sha256(raw).hexdigest() == g["sha256"], name
 
 
+# ------------------------------------------------------------------ Tier 3: the unmodified reference binary's own band
+
+def _tier3_runs(seeds, fields, tr, inclusive):
+    L = orc.lib()
+    L.orc_set_inclusive_range(1 if inclusive else 0, tr.nnz)
+    try:
+        out = []
+        for seed in seeds:
+            f2 = list(fields)
+            f2[4] = seed
+            cfg = _cfg(f2)
+            P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, cfg.n_factors)
+            log = orc.train(tr, tr, cfg, P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_SEQ, acc=orc.ACC_F32, schedule=orc.SCHED_SEQUENTIAL)
+            out.append({e["iteration"]: e for e in log})
+        return out
+    finally:
+        L.orc_set_inclusive_range(0, 0)
+
+
+def test_oracle_trajectory_lies_in_the_unmodified_reference_band():
+    """SURVEY.md section 8c, Tier 3.  The UNMODIFIED reference CPU twin seeds a fresh std::random_device per update and draws from an
+    INCLUSIVE range (mf_sequential.cu:109-112): no seed reaches its sampler, identical runs differ, and with probability 1 / (n + 1) a
+    user trains on the next user's first rating.  tests/golden/ref_tier3_band.json holds min / max of its printed train RMSE / MAE
+    over 8 runs on the reference's bundled ml-latest-small at f=10, lr .01, reg .02, at iterations 1 and 500 (oracle/gen_golden.py).
+    (a) The oracle's arithmetic (pinned bit for bit above) driven by a sampler with the reference's DISTRIBUTION -- counter-based
+        draws from the inclusive range, orc_set_inclusive_range -- follows the same trajectory: for five seeds, train RMSE and MAE
+        at both iterations lie inside the band widened by 5e-4 (the reference's own run-to-run spread is +-4.5e-4).
+    (b) The sampler the product uses everywhere -- the half-open range of sgd.cu:37, i.e. WITHOUT the reference's off-by-one --
+        converges slightly faster: its mean train RMSE after 500 iterations sits 0.2e-3 .. 1.5e-3 BELOW the reference's mean
+        (measured: 0.87283 against 0.87358; the inclusive emulation accounts for most of it: 0.87329).  Stated, not hidden."""
+    if not os.path.exists(ML_SMALL):
+        pytest.skip("reference dataset not present on this machine")
+    gold = _load("ref_tier3_band.json")
+    assert gold["runs"] >= 6
+    tr = orc.read_csv(ML_SMALL)
+    slack = 5e-4
+    for seen in _tier3_runs((42, 7, 20240917, 3, 11), gold["cfg"], tr, inclusive=True):
+        for it in (1, 500):
+            band, e = gold["band"][str(it)], seen[it]
+            assert band["rmse"]["min"] - slack <= e["train_rmse"] <= band["rmse"]["max"] + slack, (it, e["train_rmse"], band["rmse"])
+            assert band["mae"]["min"] - slack <= e["train_mae"] <= band["mae"]["max"] + slack, (it, e["train_mae"], band["mae"])
+    half_open = _tier3_runs(range(1, 9), gold["cfg"], tr, inclusive=False)
+    ref_mean = float(np.mean(gold["band"]["500"]["rmse"]["runs"]))
+    ours = float(np.mean([s[500]["train_rmse"] for s in half_open]))
+    assert 2e-4 <= ref_mean - ours <= 1.5e-3, (ref_mean, ours)
+    first = float(np.mean([s[1]["train_rmse"] for s in half_open]))
+    assert abs(first - float(np.mean(gold["band"]["1"]["rmse"]["runs"]))) <= 5e-4  # one iteration in, the two samplers have not parted yet
+
+
 # ------------------------------------------------------------------ internal consistency of the two dot orders
 
 def test_tree16_order_close_to_reference_order():
