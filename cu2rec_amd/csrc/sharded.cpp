@@ -224,152 +224,31 @@ Comm *comm_from_callback(cu2rec_allreduce_fn fn, void *ctx, int rank, int nranks
     return c;
 }
 
-// ------------------------------------------------------------------------------------------------------------ ShardJob
-ShardJob::ShardJob(Comm &comm_, DeviceModel &model_, const DeviceCsr &train_, int user_offset_,
-                   const cu2rec_shard_options &opt)
-    : comm(comm_), model(model_), train(train_), user_offset(user_offset_), sync_every(opt.sync_every), merge(opt.merge) {
-    require(train.rows <= model.rows && train.max_item < model.cols, "cu2rec_shard_job: ratings exceed the model's shape");
-    require(merge == CU2REC_MERGE_MEAN || merge == CU2REC_MERGE_WEIGHTED || merge == CU2REC_MERGE_SUM || merge == CU2REC_MERGE_ADAPTIVE,
-            "cu2rec_shard_job: unknown merge");
-    require(user_offset >= 0, "cu2rec_shard_job: negative user offset");
-    require_device();
-    const size_t nq = static_cast<size_t>(model.cols) * model.ldq;
-    Q_base.allocate(std::max<size_t>(nq, 4));
-    ib_base.allocate(std::max(model.cols, 1));
-    wire.allocate(std::max<size_t>(static_cast<size_t>(model.cols) * (model.n_factors + 1), 4));
-    sums.allocate(4);
-    CU2REC_HIP(hipMemcpy(Q_base.ptr, model.Q.ptr, nq * sizeof(float), hipMemcpyDeviceToDevice));
-    CU2REC_HIP(hipMemcpy(ib_base.ptr, model.item_bias.ptr, static_cast<size_t>(model.cols) * sizeof(float), hipMemcpyDeviceToDevice));
-    // population totals (the epoch length) and, for the weighted merge, every item's expected updates per iteration
-    double totals[2] = {static_cast<double>(train.users_with_ratings), static_cast<double>(train.nnz)};
-    CU2REC_HIP(hipMemcpy(sums.ptr, totals, sizeof(totals), hipMemcpyHostToDevice));
-    comm.allreduce(sums.ptr, 2, true, nullptr);
-    comm.wait(nullptr);
-    CU2REC_HIP(hipMemcpy(totals, sums.ptr, sizeof(totals), hipMemcpyDeviceToHost));
-    users_total = totals[0];
-    nnz_total = totals[1];
-    if (sync_every <= 0)  // "each epoch" (north star): one epoch = nnz / users iterations, SURVEY.md section 8e
-        sync_every = std::max(1, static_cast<int>(std::lround(nnz_total / std::max(users_total, 1.0))));
-    if ((merge == CU2REC_MERGE_WEIGHTED || merge == CU2REC_MERGE_ADAPTIVE) && comm.nranks > 1) {
-        // w_k[y] = rate_k[y] / sum_j rate_j[y], rate = sum over the shard's raters of 1 / degree (host, double: the same
-        // bits every run); items nobody rates anywhere keep weight 1 / N (their delta is zero anyway)
-        std::vector<int> indptr(static_cast<size_t>(train.rows) + 1), indices(static_cast<size_t>(std::max(train.nnz, 1)));
-        CU2REC_HIP(hipMemcpy(indptr.data(), train.indptr.ptr, indptr.size() * sizeof(int), hipMemcpyDeviceToHost));
-        if (train.nnz) CU2REC_HIP(hipMemcpy(indices.data(), train.indices.ptr, static_cast<size_t>(train.nnz) * sizeof(int), hipMemcpyDeviceToHost));
-        std::vector<double> rate(static_cast<size_t>(std::max(model.cols, 1)), 0.0);
-        for (int u = 0; u < train.rows; ++u) {
-            const int low = indptr[u], high = indptr[u + 1];
-            for (int k = low; k < high; ++k) rate[indices[k]] += 1.0 / (high - low);
-        }
-        DeviceBuffer<double> all(rate.size());
-        all.upload(rate.data(), rate.size());
-        comm.allreduce(all.ptr, rate.size(), true, nullptr);
-        std::vector<double> total(rate.size());
-        comm.wait(nullptr);
-        all.download(total.data(), total.size());
-        std::vector<float> w(rate.size());
-        if (merge == CU2REC_MERGE_WEIGHTED) {
-            for (size_t y = 0; y < rate.size(); ++y) w[y] = static_cast<float>(total[y] > 0 ? rate[y] / total[y] : 1.0 / comm.nranks);
-        } else {
-            // Adaptive: the deltas are SUMMED and scaled per item by alpha = phi(r_total) / sum_k phi(r_k), phi(r) = 1 - exp(-c r):
-            // a shard's delta of an item row is, to first order, the progress phi of its own updates towards a common
-            // target, and all shards' updates in sequence would make phi of the total -- alpha is 1 for an item that is
-            // rarely updated (the sum is what the sequential run does) and 1 / N for an item every shard updates many times
-            // per iteration (the mean).  c = 6 fitted on the ML-20M shape (tools/shard_study.py, profiles/r02_shard_study_*).
-            double c = 6.0;
-            if (const char *env = std::getenv("CU2REC_MERGE_ADAPTIVE_C")) c = std::max(1e-3, std::atof(env));
-            std::vector<double> phi(rate.size());
-            for (size_t y = 0; y < rate.size(); ++y) phi[y] = -std::expm1(-c * rate[y]);
-            all.upload(phi.data(), phi.size());
-            comm.allreduce(all.ptr, phi.size(), true, nullptr);
-            comm.wait(nullptr);
-            all.download(phi.data(), phi.size());  // now the sum over the ranks
-            for (size_t y = 0; y < rate.size(); ++y) w[y] = static_cast<float>(phi[y] > 0 ? -std::expm1(-c * total[y]) / phi[y] : 1.0);
-        }
-        weight.allocate(w.size());
-        weight.upload(w.data(), w.size());
-    }
+// ----------------------------------------------------------------------------------------------- the driver's HIP backend
+// (the driver itself -- cadence, exchange, merge weights, loss reduction, train() over all ranks -- is the template in
+// shard_driver.hpp; tests/host_shard/ instantiates the same template over host memory)
+void HipBackend::csr_structure(const DeviceCsr &c, std::vector<int> &indptr, std::vector<int> &indices) {
+    indptr.resize(static_cast<size_t>(c.rows) + 1);
+    indices.resize(static_cast<size_t>(std::max(c.nnz, 1)));
+    CU2REC_HIP(hipMemcpy(indptr.data(), c.indptr.ptr, indptr.size() * sizeof(int), hipMemcpyDeviceToHost));
+    if (c.nnz) CU2REC_HIP(hipMemcpy(indices.data(), c.indices.ptr, static_cast<size_t>(c.nnz) * sizeof(int), hipMemcpyDeviceToHost));
 }
 
-float ShardJob::scale() const {
-    return merge == CU2REC_MERGE_MEAN ? 1.f / static_cast<float>(comm.nranks) : 1.f;  // weighted / adaptive: in the weights
-}
-
-void ShardJob::exchange(hipStream_t stream) {
-    since_sync = 0;
-    if (comm.nranks == 1 && !comm.nccl) return;
-    launch_items_wire_pack(model.Q.ptr, model.item_bias.ptr, Q_base.ptr, ib_base.ptr, weight.ptr, model.cols, model.n_factors,
-                           model.ldq, wire.ptr, stream);
+void HipBackend::wire_pack(const float *Q, const float *ib, const float *Q_base, const float *ib_base, const float *weight, int n_cols, int f,
+                           int ldq, float *wire, hipStream_t s) {
+    launch_items_wire_pack(Q, ib, Q_base, ib_base, weight, n_cols, f, ldq, wire, s);
     CU2REC_HIP(hipGetLastError());
-    comm.allreduce(wire.ptr, static_cast<size_t>(model.cols) * (model.n_factors + 1), false, stream);
-    launch_items_wire_apply(model.Q.ptr, model.item_bias.ptr, Q_base.ptr, ib_base.ptr, model.cols, model.n_factors, model.ldq,
-                            wire.ptr, scale(), stream);
+}
+
+void HipBackend::wire_apply(float *Q, float *ib, float *Q_base, float *ib_base, int n_cols, int f, int ldq, const float *wire, float scale,
+                            hipStream_t s) {
+    launch_items_wire_apply(Q, ib, Q_base, ib_base, n_cols, f, ldq, wire, scale, s);
     CU2REC_HIP(hipGetLastError());
-    ++exchanges;
 }
 
-void ShardJob::run(const cu2rec_hyper &h, uint64_t seed, uint64_t iter0, int n_iters, int mode, int update_items,
-                   hipStream_t stream) {
-    require(n_iters >= 0, "cu2rec_shard_job_run: bad iteration count");
-    require(mode != CU2REC_SGD_PINGPONG, "cu2rec_shard_job_run: the ping-pong mode swaps item buffers and is single-GPU only");
-    int done = 0;
-    while (done < n_iters) {
-        const int n = std::min(n_iters - done, sync_every - since_sync);
-        model.sgd(train, h, seed, iter0 + static_cast<uint64_t>(done), n, mode, update_items, stream, false, user_offset);
-        done += n;
-        since_sync += n;
-        if (since_sync >= sync_every) {
-            // the period ends whether or not anything moved: with frozen items nothing is exchanged, but the counter
-            // starts over (or n would stay 0 for ever)
-            if (update_items) exchange(stream);
-            else since_sync = 0;
-        }
-    }
-}
-
-void ShardJob::loss(const DeviceCsr &ratings, double *sum_abs, double *sum_sq, double *n_total, float *mae, float *rmse,
-                    hipStream_t stream) {
-    double host[3] = {0.0, 0.0, static_cast<double>(ratings.nnz)};
-    // the wire all-reduce of an exchange may still be queued on `stream`, and the loss pass ends in a plain
-    // hipStreamSynchronize: wait for it HERE, bounded (Comm::wait polls ncclCommGetAsyncError and gives up after
-    // CU2REC_COMM_TIMEOUT_S), or a dead peer would hold this rank inside that synchronize for ever
-    if (comm.nranks > 1) comm.wait(stream);
-    model.loss(ratings, &host[0], &host[1], nullptr, nullptr, stream);
-    if (comm.nranks > 1) {
-        CU2REC_HIP(hipMemcpyAsync(sums.ptr, host, sizeof(host), hipMemcpyHostToDevice, stream));
-        comm.allreduce(sums.ptr, 3, true, stream);
-        CU2REC_HIP(hipMemcpyAsync(host, sums.ptr, sizeof(host), hipMemcpyDeviceToHost, stream));
-        comm.wait(stream);  // (bounded: a dead peer ends the call, not the night)
-    }
-    if (sum_abs) *sum_abs = host[0];
-    if (sum_sq) *sum_sq = host[1];
-    if (n_total) *n_total = host[2];
-    if (mae) *mae = static_cast<float>(host[0] / host[2]);              // loss.cu:189
-    if (rmse) *rmse = static_cast<float>(std::sqrt(host[1] / host[2]));
-}
-
-// train() (training.h:12-15) over all ranks: the same observable schedule as cu2rec_train -- loss on train and test at
-// i == 0, every check_error and last, the TRAIN: / TEST: lines (rank 0), patience / learning-rate decay on the GLOBAL
-// test RMSE (identical on every rank: the loss sums are all-reduced), cfg.learning_rate / cfg.cur_iterations updated.
 void train_sharded(ShardJob &job, const DeviceCsr &test, cu2rec_config &cfg, int mode, bool verbose, float *losses,
                    cu2rec_train_stats *stats) {
-    require(cfg.n_factors == job.model.n_factors, "cu2rec_train_sharded: cfg.n_factors differs from the model's");
-    require(test.rows <= job.model.rows && test.max_item < job.model.cols,
-            "cu2rec_train_sharded: test ratings name users/items the model does not have");
-    hipStream_t stream = nullptr;
-    const uint64_t seed = static_cast<uint64_t>(static_cast<uint32_t>(cfg.seed));
-    train_schedule(
-        cfg, verbose, job.comm.rank == 0, job.users_total, losses, stats, stream,
-        [&](const cu2rec_hyper &h, uint64_t first, int n, hipStream_t s) {
-            job.run(h, seed, first, n, mode, cfg.is_train, s);
-            // a loss check follows: every replica must hold the same item side (an exchange out of cadence, like the
-            // Python driver's exchange(final=True))
-            if (cfg.is_train && job.since_sync > 0) job.exchange(s);
-        },
-        [&](bool on_train, float *mae, float *rmse) {
-            job.loss(on_train ? job.train : test, nullptr, nullptr, nullptr, mae, rmse, stream);
-        },
-        [] {});
+    shard_train<HipBackend>(job, test, cfg, mode, verbose, losses, stats);
 }
 
 }  // namespace cu2rec
@@ -459,7 +338,7 @@ int cu2rec_shard_job_info(const cu2rec_shard_job *job, int *sync_every, int *exc
         if (exchanges) *exchanges = job->impl.exchanges;
         if (users_total) *users_total = job->impl.users_total;
         if (nnz_total) *nnz_total = job->impl.nnz_total;
-        if (wire_bytes) *wire_bytes = static_cast<size_t>(job->impl.model.cols) * (job->impl.model.n_factors + 1) * sizeof(float);
+        if (wire_bytes) *wire_bytes = job->impl.wire_floats() * sizeof(float);
     });
 }
 

@@ -1,93 +1,38 @@
-// The reference's training schedule (training.cu:101-177) as a template over "run these iterations" and "evaluate the
-// loss": cu2rec_train (one GPU) and cu2rec_train_sharded (one process per GPU) are the same loop.
+// The reference's training schedule (training.cu:101-177) on the GPU: train_schedule_core.hpp's loop with HIP events on the
+// launch stream as its clock.
 #pragma once
 
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <limits>
-
 #include "device.hpp"
+#include "train_schedule_core.hpp"
 
 namespace cu2rec {
 
-struct EventPair {
-    hipEvent_t start = nullptr, stop = nullptr;
-    EventPair() {
-        CU2REC_HIP(hipEventCreate(&start));
-        CU2REC_HIP(hipEventCreate(&stop));
+struct HipClock {  // the SGD stretch between two loss checks, by events on the stream it is queued on
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    HipClock() {
+        CU2REC_HIP(hipEventCreate(&ev_start));
+        CU2REC_HIP(hipEventCreate(&ev_stop));
     }
-    ~EventPair() {
-        if (start) (void)hipEventDestroy(start);
-        if (stop) (void)hipEventDestroy(stop);
+    HipClock(const HipClock &) = delete;
+    HipClock &operator=(const HipClock &) = delete;
+    ~HipClock() {
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_stop) (void)hipEventDestroy(ev_stop);
     }
+    void start(hipStream_t s) { CU2REC_HIP(hipEventRecord(ev_start, s)); }
+    void stop(hipStream_t s) { CU2REC_HIP(hipEventRecord(ev_stop, s)); }
+    float elapsed_ms() {
+        float ms = 0.f;
+        CU2REC_HIP(hipEventElapsedTime(&ms, ev_start, ev_stop));
+        return ms;
+    }
+    void drain() { CU2REC_HIP(hipDeviceSynchronize()); }
 };
 
-inline bool is_check_iteration(int i, const cu2rec_config &cfg) {  // training.cu:118
-    return (i + 1) % cfg.check_error == 0 || i == 0 || (i + 1) % cfg.total_iterations == 0;
-}
-
-// sgd(hyper, first_iteration, n, stream): queue n iterations; loss(train?, &mae, &rmse): evaluate on train / test (blocking);
-// after_check(): what follows a loss check (CU2REC_SGD_PINGPONG's deferred swap).  `print`: this rank writes the lines.
 template <class Sgd, class Loss, class After>
 void train_schedule(cu2rec_config &cfg, bool verbose, bool print, double updates_per_iteration, float *losses,
                     cu2rec_train_stats *stats, hipStream_t stream, Sgd sgd, Loss loss, After after_check) {
-    require(cfg.total_iterations >= 0 && cfg.check_error > 0, "cu2rec_train: bad iteration counts");
-    const int total = cfg.total_iterations;
-    if (losses)
-        for (int i = 0; i < total; ++i) losses[i] = std::numeric_limits<float>::quiet_NaN();
-    EventPair ev;
-    cu2rec_train_stats st{};
-    float train_mae = 0.f, train_rmse = 0.f, validation_mae, validation_rmse, last_validation_rmse;
-    validation_rmse = validation_mae = std::numeric_limits<float>::max();  // training.cu:102
-    int current_patience = static_cast<int>(cfg.patience);                 // training.cu:103
-    const uint64_t iter_base = static_cast<uint64_t>(cfg.cur_iterations);
-
-    const auto t0 = std::chrono::steady_clock::now();  // training.cu:106 (clock() there; wall clock here)
-    int i = 0;
-    while (i < total) {
-        // queue every iteration up to and including the next loss check
-        int seg_end = i;
-        while (!is_check_iteration(seg_end, cfg)) ++seg_end;
-        const int n = seg_end - i + 1;
-        const cu2rec_hyper h{cfg.learning_rate, cfg.P_reg, cfg.Q_reg, cfg.user_bias_reg, cfg.item_bias_reg};
-        CU2REC_HIP(hipEventRecord(ev.start, stream));
-        sgd(h, iter_base + static_cast<uint64_t>(i), n, stream);
-        CU2REC_HIP(hipEventRecord(ev.stop, stream));
-
-        // training.cu:121-137: loss on train then test, printed in the reference's format
-        loss(true, &train_mae, &train_rmse);
-        last_validation_rmse = validation_rmse;  // training.cu:129
-        loss(false, &validation_mae, &validation_rmse);
-        float ms = 0.f;
-        CU2REC_HIP(hipEventElapsedTime(&ms, ev.start, ev.stop));
-        st.seconds_sgd += 1e-3 * ms;
-        st.n_checks += 1;
-        if (verbose && print) {
-            std::printf("TRAIN: Iteration %d GPU MAE: %f RMSE: %f\n", seg_end + 1, train_mae, train_rmse);
-            std::printf("TEST: Iteration %d GPU MAE: %f RMSE: %f\n", seg_end + 1, validation_mae, validation_rmse);
-        }
-        // training.cu:146-155: patience is consumed when the test RMSE got worse, never restored on improvement
-        if (last_validation_rmse < validation_rmse) current_patience--;
-        if (current_patience <= 0) {
-            current_patience = static_cast<int>(cfg.patience);
-            cfg.learning_rate *= cfg.learning_rate_decay;
-            if (verbose && print) std::printf("New Learning Rate: %f\n: ", cfg.learning_rate);
-        }
-        after_check();                                   // training.cu:164-165 (no-op outside CU2REC_SGD_PINGPONG)
-        if (losses) losses[seg_end] = validation_rmse;  // training.cu:158
-        cfg.cur_iterations += n;                         // training.cu:170
-        i = seg_end + 1;
-    }
-    CU2REC_HIP(hipDeviceSynchronize());  // training.cu:172
-    st.seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (verbose && print) std::printf("Time taken for %d of iterations is %lf\n", total, st.seconds_total);  // training.cu:177
-    st.updates = updates_per_iteration * total;
-    st.last_train_mae = train_mae;
-    st.last_train_rmse = train_rmse;
-    st.last_test_mae = validation_mae;
-    st.last_test_rmse = validation_rmse;
-    if (stats) *stats = st;
+    train_schedule_with<HipClock>(cfg, verbose, print, updates_per_iteration, losses, stats, stream, sgd, loss, after_check);
 }
 
 }  // namespace cu2rec
