@@ -98,6 +98,7 @@ SIGNATURES = {
     "cu2rec_blocksolve_min_rate": (C.c_float, [C.c_float]),
     "cu2rec_blocksolve_affine_blocks": (C.c_int, [C.c_int]),
     "cu2rec_blocksolve_lookahead_blocks": (C.c_int, [C.c_int]),
+    "cu2rec_ordered_persistent_launches": (C.c_int, []),
     "cu2rec_blocksolve_affine_head": (C.c_int, [C.c_int]),
     "cu2rec_csr_blocksolve_items": (C.c_int, [_P]),
     "cu2rec_debug_blocksolve_stamps": (C.c_int, [_P, C.c_int]),

@@ -569,6 +569,7 @@ float cu2rec_blocksolve_min_rate(float rate) { return blocksolve_min_rate(rate);
 int cu2rec_blocksolve_affine_blocks(int blocks) { return blocksolve_affine_blocks(blocks); }
 int cu2rec_blocksolve_affine_head(int blocks) { return blocksolve_affine_head(blocks); }
 int cu2rec_blocksolve_lookahead_blocks(int blocks) { return blocksolve_lookahead_blocks(blocks); }
+int cu2rec_ordered_persistent_launches(void) { return ordered_persistent_launches(); }
 
 int cu2rec_csr_blocksolve_items(const cu2rec_csr *train) {
     int n = -1;

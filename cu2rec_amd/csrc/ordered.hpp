@@ -98,6 +98,8 @@ float blocksolve_min_rate(float rate);
 float blocksolve_min_rate_base();   // the explicit value, or the default the automatic scaling starts from
 bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwise a schedule scales the default with its set
 
+// persistent ordered launches queued so far in this process (CU2REC_ORDERED_PERSISTENT=1; tests check that the form really ran)
+int ordered_persistent_launches();
 // chains EXPECTED to be at least this many blocks of 64 links long run phase 2 in the look-ahead form (0: none, the default;
 // schedules created later); blocks < 0 only queries
 int blocksolve_lookahead_blocks(int blocks);

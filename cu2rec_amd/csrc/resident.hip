@@ -47,6 +47,7 @@
 #include "hip_check.hpp"
 #include "kernels.hpp"
 #include "resident.hpp"
+#include "grid_barrier.hpp"
 #include "sampler.hpp"
 #include "sgd_device.hpp"
 
@@ -67,19 +68,9 @@ using namespace dev;
 
 constexpr int kResBlock = 512;                    // 8 wavefronts = 2 per SIMD: up to 256 VGPRs each
 constexpr int kResGroups = kResBlock / kGroup;    // 32 user groups per workgroup
-constexpr unsigned long long kBarrierTimeoutTicks = 300000000ull;  // 3 s of the 100 MHz wall clock
 constexpr int kXcds = 8;                          // XCDs of an MI355X (single-XCD launches: cus / 8 workgroups run)
 
-// Barrier words, each on a 128-byte line of its own (indices into an array of unsigned, zeroed before every launch):
-constexpr int kLine = 32;
-constexpr int kMaxXcc = 16;
-constexpr int kWTop = 0;                                  // XCD leaders that have released, summed over phases
-constexpr int kWCensusTop = kLine;                        // workgroups that have reported their XCD
-constexpr int kWCensus = 2 * kLine;                       // [x]: workgroups on XCD x
-constexpr int kWArrive = kWCensus + kMaxXcc * kLine;      // [x]: arrivals on XCD x, summed over phases
-constexpr int kWGen = kWArrive + kMaxXcc * kLine;         // [x]: last phase XCD x may leave
-constexpr int kWTarget = kWGen + kMaxXcc * kLine;         // single-XCD launches: 1 + the XCD that runs them (workgroup 0's)
-constexpr int kBarrierWords = kWTarget + kLine;
+using namespace gridbar;  // the barrier: grid_barrier.hpp
 
 struct ResidentArgs {
     unsigned *words;       // the barrier block above (device memory)
@@ -89,105 +80,6 @@ struct ResidentArgs {
 };
 constexpr int kSinkBias = 512;                 // sink[0 .. 511]: an item row, sink[512]: an item bias
 constexpr int kSinkFloats = kSinkBias + 16;
-
-struct BarrierShared {  // per workgroup, in LDS; written by thread 0 only
-    int xcc, n_mine, n_xcds, leader, ok;
-    int part, index;  // single-XCD launches: does this workgroup take part, and its number among those that do
-};
-
-__device__ __forceinline__ unsigned ld_relaxed(const unsigned *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load sc1: never L1-served
-}
-
-// Spins until *p - target >= 0 (wrap-safe); false if the status word is set or 3 s have passed (then sets it).
-__device__ __forceinline__ bool spin_until(const unsigned *p, unsigned target, unsigned *status) {
-    const unsigned long long t0 = wall_clock64();
-    unsigned polls = 0;
-    while (static_cast<int>(ld_relaxed(p) - target) < 0) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++polls & 63u) == 0 && (ld_relaxed(status) != 0 || wall_clock64() - t0 > kBarrierTimeoutTicks)) {
-            __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-    }
-    return true;
-}
-
-// Once per launch, thread 0 of every workgroup: which XCD am I on, how many workgroups share it, how many XCDs
-// are in use.  (Placement is the dispatcher's business; the barrier only needs the counts.)
-__device__ __forceinline__ void barrier_census(const ResidentArgs &ra, BarrierShared *bs) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= kMaxXcc - 1;
-    // The per-XCD count must be visible before the top count can reach gridDim.x: the second add is a RELEASE (it may
-    // not overtake the first, which sits on another cache line), and a reader that has seen the full top count takes an
-    // ACQUIRE before it reads the per-XCD counts.  With two relaxed adds a workgroup could see "everybody has arrived"
-    // while the last per-XCD add was still in flight, undercount its XCD and open the barrier early.
-    const unsigned mine = __hip_atomic_fetch_add(ra.words + kWCensus + xcc * kLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ra.local && blockIdx.x == 0)  // (relaxed: ordered in front of the release below like the per-XCD count)
-        __hip_atomic_store(ra.words + kWTarget, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(ra.words + kWCensusTop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    bs->ok = spin_until(ra.words + kWCensusTop, gridDim.x, ra.status) ? 1 : 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    int n_xcds = 0;
-    for (int x = 0; x < kMaxXcc; ++x) n_xcds += ld_relaxed(ra.words + kWCensus + x * kLine) != 0;
-    bs->xcc = static_cast<int>(xcc);
-    bs->n_mine = static_cast<int>(ld_relaxed(ra.words + kWCensus + xcc * kLine));
-    bs->n_xcds = n_xcds;
-    bs->part = 1;
-    bs->index = static_cast<int>(mine);
-    if (ra.local) {  // the barrier is that of ONE XCD from here on: its workgroups, numbered in the order they reported
-        bs->part = ld_relaxed(ra.words + kWTarget) == xcc + 1u ? 1 : 0;
-        bs->n_xcds = 1;
-    }
-}
-
-// Grid barrier, split in two so that work which does not depend on other workgroups (the next iteration's sample
-// gathers) runs while the chip drains.  XCD-hierarchical: the LAST workgroup to arrive on an XCD is its leader and
-// does the one agent-scope release (L2 write-back) for that XCD -- every other workgroup of the XCD has drained its
-// stores into that same L2 before it arrived -- then reports to the top counter, waits for all XCDs and opens its
-// XCD's generation word; the others only poll that word.  Everybody ends with an agent-scope acquire (L1 invalidate).
-__device__ __forceinline__ void barrier_arrive(const ResidentArgs &ra, unsigned phase, BarrierShared *bs) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's item-row stores have reached L2
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(ra.words + kWArrive + bs->xcc * kLine, 1u, __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT);
-        const bool leader = old + 1 == phase * static_cast<unsigned>(bs->n_mine);
-        if (leader) {
-            if (!(CU2REC_RES_ABLATE & 64) && !ra.local)             // 64: timing only, no L2 write-back
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines (a single-XCD
-                                                                    // launch shares ONE L2: nothing to write back)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the compiler may drop its own wait here)
-            __hip_atomic_fetch_add(ra.words + kWTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        bs->leader = leader ? 1 : 0;
-        // The acquire half, early: invalidate this CU's L1 NOW, so that it overlaps the wait below.  Between here and the
-        // end of barrier_wait no wave of this workgroup loads an item row or item bias (only the read-only sample arrays),
-        // so nothing another CU rewrites can enter the L1 again before the barrier has passed, and the first item-row
-        // loads after it miss the L1 and are served by the L2, which the XCD leaders' releases have made current.
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-}
-
-// true: everybody arrived.  false: gave up (status word set); the caller leaves its iteration loop.
-__device__ __forceinline__ bool barrier_wait(const ResidentArgs &ra, unsigned phase, BarrierShared *bs) {
-    if (threadIdx.x == 0) {
-        bool ok;
-        unsigned *gen = ra.words + kWGen + bs->xcc * kLine;
-        if (bs->leader) {
-            ok = spin_until(ra.words + kWTop, phase * static_cast<unsigned>(bs->n_xcds), ra.status);
-            __hip_atomic_store(gen, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            ok = spin_until(gen, phase, ra.status);
-        }
-        if (!(CU2REC_RES_ABLATE & 128))                         // 128: timing only, no L1 invalidate
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate issued in barrier_arrive has completed
-        bs->ok = ok ? 1 : 0;
-    }
-    __syncthreads();
-    return bs->ok != 0;
-}
 
 // A lane's float4 slots of a row, "wrapped": where lane + 16 j runs past the row (f = 100: the second slot of lanes
 // 9..15) the lane holds a DUPLICATE of a real slot instead of padding.  Duplicates are loaded from, updated like
@@ -549,6 +441,28 @@ int resident_policy(int set_to) {
     return prev;
 }
 
+GridBarrierBlock grid_barrier_begin(hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState &s = state_for_current_device();
+    if (s.have_last && s.last_stream != stream) CU2REC_HIP(hipStreamWaitEvent(stream, s.done, 0));  // never two at once
+    CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));               // counters start from zero
+    GridBarrierBlock b;
+    b.words = s.words;
+    b.status = s.words + kBarrierWords;
+    b.cooperative = s.cooperative;
+    b.cus = s.cus;
+    return b;
+}
+
+void grid_barrier_end(hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceState &s = state_for_current_device();
+    CU2REC_HIP(hipMemcpyAsync(s.host_status, s.words + kBarrierWords, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    CU2REC_HIP(hipEventRecord(s.done, stream));
+    s.last_stream = stream;
+    s.have_last = true;
+}
+
 void resident_check_fault() {
     std::lock_guard<std::mutex> lock(g_mutex);
     int dev = 0;
@@ -564,9 +478,9 @@ void resident_check_fault() {
         (void)hipMemset(s.words + kBarrierWords, 0, sizeof(unsigned));
         *s.host_status = 0;
         fail(CU2REC_EHIP,
-             "cu2rec_amd: a resident SGD launch gave up at its grid barrier (the grid was not co-resident: is another "
-             "process or stream using this GPU?); the model state is undefined.  CU2REC_RESIDENT=0 selects the "
-             "one-launch-per-iteration kernel");
+             "cu2rec_amd: a persistent SGD launch gave up at its grid barrier (the grid was not co-resident: is another "
+             "process or stream using this GPU?); the model state is undefined.  CU2REC_RESIDENT=0 (Hogwild) / "
+             "CU2REC_ORDERED_PERSISTENT=0 (ordered mode, small sets) select the one-launch-per-iteration kernels");
     }
 }
 

@@ -32,6 +32,19 @@ bool resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *u
 // Launches the runtime refused on the current device because the grid could not be co-resident (those calls streamed).
 int resident_refusals();
 
+// The device's ONE grid-barrier block (grid_barrier.hpp), shared by every persistent launch of the library -- the resident Hogwild
+// launches here and the persistent ordered launches of ordered.hip: never two of them at once.  grid_barrier_begin waits (on
+// `stream`) for the previous user's end, zeroes the counters and hands out the block; grid_barrier_end queues the status word's
+// copy to the host behind the launch and marks the block's next user's start.  cooperative: may the launch be a cooperative one
+// (hipLaunchCooperativeKernel: the runtime refuses a grid that cannot be co-resident).
+struct GridBarrierBlock {
+    unsigned *words = nullptr, *status = nullptr;
+    bool cooperative = false;
+    int cus = 0;
+};
+GridBarrierBlock grid_barrier_begin(hipStream_t stream);
+void grid_barrier_end(hipStream_t stream);
+
 // Throws if an earlier resident launch on the current device gave up at a grid barrier (bounded spin).
 void resident_check_fault();
 

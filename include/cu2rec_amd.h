@@ -299,6 +299,11 @@ int cu2rec_blocksolve_affine_head(int blocks);
  * up to float rounding.  Process-wide, read when a schedule is created (like cu2rec_blocksolve_min_rate); 0 = off (default);
  * CU2REC_BLOCKSOLVE_LOOKAHEAD in the environment sets the initial value.  Returns the previous value; blocks < 0 only queries. */
 int cu2rec_blocksolve_lookahead_blocks(int blocks);
+/* Ordered mode on SMALL sets, opt-in (CU2REC_ORDERED_PERSISTENT=1 in the environment): all iterations of a schedule batch in ONE
+ * persistent launch, a grid barrier where training.cu:107-115 has its kernel boundaries (only when a whole iteration's grid is
+ * co-resident; bit-identical results).  Measured slower than the launch per iteration on the ML-1M shape (18.1 against 15.6 us),
+ * hence not the default.  Returns how many such launches this process has queued so far. */
+int cu2rec_ordered_persistent_launches(void);
 /* Development aid: while `buffer` (device memory, 8 * (1 + 8 * capacity) bytes, zeroed by the caller) is set, every
  * wavefront of the block-solve kernels writes {kernel, id, start, end, 4 marks (trace builds)} in ticks of the 100 MHz device clock into record
  * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 5 walk, 6 affine builder, 7 cross blocks; records never written stay

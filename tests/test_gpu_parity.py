@@ -707,3 +707,36 @@ def test_two_logical_shards_on_one_gpu_match_the_oracle():
         np.testing.assert_array_equal(gub, oub[k][u0:u1])
         np.testing.assert_array_equal(gQ, Qb)
         np.testing.assert_array_equal(gib, ibb)
+
+
+def test_ordered_persistent_launch_is_the_oracle_bit_for_bit():
+    """CU2REC_ORDERED_PERSISTENT=1 (opt-in; read once per process, hence a process of its own): a small set's ordered iterations as
+    ONE persistent launch per schedule batch, a grid barrier where the kernel boundaries were (sgd_ordered_persistent_kernel).  70
+    iterations (two batches) of a 3,000-user set with popular items (two-wave chains AND the walk): every parameter equal to the
+    sequential oracle's bit for bit -- a stale user row behind a barrier would change bits."""
+    import subprocess
+    import sys
+    script = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import cu2rec_amd as cu
+from cu2rec_amd import synth
+from cu2rec_amd._lib import check, lib
+from oracle import oracle as orc
+tr, _ = synth.make_ratings(3000, 40, 30000, min_degree=3, seed=77)
+f, hyper = 50, (0.01, 0.02, 0.02, 0.02, 0.02)
+model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+d = cu.DeviceCSR(tr)
+model.sgd(d, hyper, 42, 0, 70, mode="ordered")
+model.sgd(d, hyper, 42, 70, 5, mode="ordered")
+check(lib().cu2rec_check_faults())
+state = orc.init_model(tr.rows, tr.cols, f)
+orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias), *state, tr.global_bias, hyper, 42, 0, 75,
+                   dot_order=orc.DOT_TREE16)
+assert lib().cu2rec_ordered_persistent_launches() >= 3, "the persistent form did not run"
+print("EQUAL" if all(np.array_equal(g, w) for g, w in zip(model.download(), state)) else "DIFFERENT")
+""" % ROOT
+    env = dict(os.environ, CU2REC_ORDERED_PERSISTENT="1")
+    res = subprocess.run([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().splitlines()[-1] == "EQUAL", res.stdout[-2000:]
