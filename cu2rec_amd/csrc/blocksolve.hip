@@ -137,8 +137,16 @@ struct WaveStamp {
     unsigned long long c0 = clock64();  // shader clock (s_memtime): with the 100 MHz wall clock, the frequency the wavefront ran at
 #endif
     __device__ __forceinline__ explicit WaveStamp(const BsIteration &it) : t0(it.stamps ? wall_clock64() : 0) {}
+    __device__ __forceinline__ void fine(const BsIteration &it, int i) {  // -DCU2REC_BS_TRACE=2: the inside of phases 1 and 3
+#if CU2REC_BS_TRACE == 2
+        if (it.stamps) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            marks[i] = wall_clock64();
+        }
+#endif
+    }
     __device__ __forceinline__ void mark(const BsIteration &it, int i) {
-#if CU2REC_BS_TRACE
+#if CU2REC_BS_TRACE == 1
         if (it.stamps) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS / scalar only: stores in flight are not part of a phase
             marks[i] = wall_clock64();
@@ -146,7 +154,7 @@ struct WaveStamp {
 #endif
     }
     __device__ __forceinline__ void span(int i, unsigned long long ticks) {  // trace builds: a duration, shown as a mark that far behind the start
-#if CU2REC_BS_TRACE
+#if CU2REC_BS_TRACE == 1
         marks[i] = t0 + ticks;
 #endif
     }
@@ -406,13 +414,18 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
     }
     __syncthreads();
     stamp.mark(it, 1);
+    stamp.fine(it, 0);  // rows gathered
     const int k = lane & 31, h = lane >> 5;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     if (wave < 3) {  // 0: G00 -> N00, 1: G11 -> N11, 2: G10 -> N10 (rows: links 32.., columns: links 0..31)
+        // D[i][j] = (A row i) . (B row j) lands in lane j = l & 31 at the rows i = acc_row(reg, h) of its registers.  The lane's own
+        // link is the tile's ROW here, the registers' index its columns -- for the diagonal tiles by symmetry, for N10 because
+        // A = links 0..31 and B = links 32..63: every lane then holds 4 x 4 CONTIGUOUS columns of its row and writes them with four
+        // 16-byte LDS stores (round 4; it was sixteen scattered 4-byte stores behind two table reads each: 3.3 us of phase 1)
         const int S0 = (nslots + 1) >> 1;  // slots per lane half
-        const float4 *ra = tile + (wave == 0 ? k : kH + k) * RS, *rb = tile + (wave == 1 ? kH + k : k) * RS;
+        const float4 *ra = tile + (wave == 1 ? kH + k : k) * RS, *rb = tile + (wave == 0 ? k : kH + k) * RS;
         for (int c = 0; c < S0; c += 2) {
             float4 va[2], vb[2];
 #pragma unroll
@@ -431,25 +444,32 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
             }
         }
     }
+    stamp.fine(it, 1);  // Gram products issued (the accumulator is read right behind)
     __syncthreads();  // every wavefront is through with the rows: the tiles take their place
     if (wave < 3) {
+        // N[K][J] = lr (c^d + a^d G[K][J]), d = K - 1 - J (links of the block), for J < K < n_valid; the powers by v_exp_f32 from
+        // log2 a, log2 c (they multiply lr-sized terms only: an ulp of the power is 1e-9 of an entry)
         const float lr = a.h.lr;
-        auto entry = [&](int d, float gram) { return lr * (tab[kB + d] + tab[d] * gram); };
+        const int K = (wave == 0 ? 0 : kH) + k;            // this lane's link: the row
+        const int J0 = (wave == 1 ? kH : 0) + 4 * h;       // first column of register 0
+        const bool row_ok = K < bd.n_valid;
+        float *dst = Ns + (wave * kH + k) * kMS + 4 * h;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int j = acc_row(reg, h);
-            if (wave < 2) {
-                // a diagonal tile is symmetric: read the lane as the link k and the register's row as j
-                const int d = max(k - 1 - j, 0);
-                Ns[(wave * kH + k) * kMS + j] = j < k && wave * kH + k < bd.n_valid ? entry(d, acc[reg]) : 0.f;
-            } else {
-                // the off-diagonal tile: register row r = link 32 + r, lane column = link k
-                Ns[(2 * kH + j) * kMS + k] = kH + j < bd.n_valid ? entry(kH + j - 1 - k, acc[reg]) : 0.f;
+        for (int m = 0; m < 4; ++m) {
+            f32x4 out;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int d = K - 1 - (J0 + 8 * m + e);
+                const float fd = static_cast<float>(d);
+                const float v = lr * (__builtin_amdgcn_exp2f(fd * it.log2c) + __builtin_amdgcn_exp2f(fd * it.log2a) * acc[4 * m + e]);
+                out[e] = d >= 0 && row_ok ? v : 0.f;
             }
+            *reinterpret_cast<f32x4 *>(dst + 8 * m) = out;
         }
     }
     __syncthreads();
     stamp.mark(it, 2);
+    stamp.fine(it, 2);  // lr L in LDS
     if (wave == 0) {
     // M11 (lanes 0-31) and M22 (lanes 32-63): lane = column, m[kk] = M[kk][column]
     float m[kH];
@@ -484,6 +504,7 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
 #pragma unroll
     for (int kk = 0; kk < kH; ++kk) Ms[(h * kH + kk) * kMS + k] = m[kk];
     __builtin_amdgcn_wave_barrier();
+    stamp.fine(it, 3);  // the two triangular inverses
     // T = N10 M11, then M21 = -M22 T
     f32x16 tacc, macc;
 #pragma unroll
@@ -1939,6 +1960,7 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
     se[lane] = e;
     sx[lane] = x;
     __builtin_amdgcn_wave_barrier();
+    stamp.fine(it, 0);  // errors, user ids, start row
     const int rsub = lane >> 3, cs = lane & 7;
     const int slot = 8 * ct + cs, slotc = min(slot, a.nslots - 1);
     {
@@ -1950,6 +1972,7 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
         for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(tile + (8 * i + rsub) * kUpdStride + 4 * cs) = v[i];
     }
     __builtin_amdgcn_wave_barrier();
+    stamp.fine(it, 1);  // the block's rows in LDS
     // operands of step s: the contraction index is 16 h + s inside a 32-link half
     float t00[16], t10[16], t11[16], b0[16], b1[16];
 #pragma unroll
@@ -1982,6 +2005,7 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(t11[s], b1[s], acc1, 0, 0, 0);
+    stamp.fine(it, 2);  // products issued
     __builtin_amdgcn_wave_barrier();  // every B operand has been read: the tile takes the new values
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1998,6 +2022,7 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
         }
     }
     __builtin_amdgcn_wave_barrier();
+    stamp.fine(it, 3);  // new rows in LDS
     if (slot < a.nslots) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

@@ -97,12 +97,18 @@ def main():
                 if kid in (2, 3):
                     for row in list(rr[:8]) + list(rr[-4:]):
                         print("     chain %d wave %d:" % (row[1] // 4, row[1] % 4), [round(float(v - row[2]) / 100.0, 2) for v in row[4:]], "end", round(float(row[3] - row[2]) / 100.0, 2))
-            if kid in (3, 4):
+            if kid in (3, 4) and not os.environ.get("CU2REC_PROBE_FINE"):
                 cyc = (r[:, 7] - r[:, 2]).astype(np.float64)
                 tick = (r[:, 3] - r[:, 2]).astype(np.float64)
                 ok = tick > 0
                 ghz = cyc[ok] / (tick[ok] * 10.0)
                 print("   shader clock over the wavefront's life: mean %.3f GHz (p10 %.3f, p90 %.3f)" % (ghz.mean(), np.percentile(ghz, 10), np.percentile(ghz, 90)))
+            if kid in (1, 4) and os.environ.get("CU2REC_PROBE_FINE") and r[:, 4:].any():
+                rr = r[(r[:, 4:] > 0).all(axis=1)]
+                mk = (rr[:, 4:] - rr[:, 2:3]) / 100.0
+                d = (rr[:, 3] - rr[:, 2]) / 100.0
+                for q in (50, 90, 100):
+                    print("   fine marks p%d:" % q, [round(float(v), 2) for v in np.percentile(mk, q, axis=0)], "end", round(float(np.percentile(d, q)), 2))
             if kid == 1:
                 order = np.argsort(-en)[:6]
                 for i in order:
