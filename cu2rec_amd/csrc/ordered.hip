@@ -44,6 +44,7 @@
 #include <map>
 #include <mutex>
 #include <numeric>
+#include <string>
 #include <vector>
 
 #include "hip_check.hpp"
@@ -959,6 +960,20 @@ std::atomic<int> g_bs_affine_blocks{-1};  // -1: not yet initialised from the en
 
 int ordered_persistent_launches() { return g_persistent_launches.load(); }
 
+// How the block-solve mode forks and joins its side stream: 2 (default) gate kernel + device-side join, 1 gate kernel + event
+// join, 0 events both ways.  CU2REC_BS_GATE in the environment decides; without it, a process running under a COUNTER pass of
+// rocprofv3 (--pmc: the tool exports ROCPROF_COUNTER_COLLECTION) takes 0 -- a counter pass serialises kernels across streams, and
+// the device-side join would wait for a signal kernel the profiler does not let run before the waiting kernel has ended.
+int bs_gate_mode() {
+    static const int mode = [] {
+        if (const char *env = std::getenv("CU2REC_BS_GATE")) return std::atoi(env);
+        if (const char *pmc = std::getenv("ROCPROF_COUNTER_COLLECTION"))
+            if (*pmc && std::string(pmc) != "0" && std::string(pmc) != "False" && std::string(pmc) != "false") return 0;
+        return 2;
+    }();
+    return mode;
+}
+
 int blocksolve_affine_blocks(int blocks) {
     int prev = g_bs_affine_blocks.load();
     if (prev < 0) {
@@ -1271,7 +1286,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.dbg = dbg;
                 if (!concurrent) {
                     it.started_target = 0;  // phase 2 is queued behind phase 1: nothing to wait for
-                    static const int gate_mode = std::getenv("CU2REC_BS_GATE") ? std::atoi(std::getenv("CU2REC_BS_GATE")) : 2;
+                    static const int gate_mode = bs_gate_mode();
                     const bool device_join = gate_mode >= 2 && n_hot_bs > 0 && max_blocks > 0 && std::getenv("CU2REC_BS_MARKERS") == nullptr;
                     if (upd_pending && !device_join) {  // join: the previous iteration's other chains may have written rows phase 1 reads
                         CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));
@@ -1281,7 +1296,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                     // (measured: 71 instead of 19 us).  Both events ride on their kernels' completion signals (CU2REC_BS_MARKERS=1:
                     // separate hipEventRecord markers as in round 2, for comparison).
                     static const bool markers = std::getenv("CU2REC_BS_MARKERS") != nullptr;
-                    static const bool gate = !(std::getenv("CU2REC_BS_GATE") != nullptr && std::atoi(std::getenv("CU2REC_BS_GATE")) == 0);  // CU2REC_BS_GATE=0: the event
+                    static const bool gate = bs_gate_mode() != 0;  // CU2REC_BS_GATE=0: the event
                     if (gate && !markers && n_hot_bs > 0 && max_blocks > 0) {  // (phase 1 is launched at all)
                         // The fork without an event: phase 1's workgroups count themselves through, and ONE wavefront queued in front
                         // of the side kernel (after phase 1 in host order: streams sharing a hardware queue serialise, they cannot

@@ -98,6 +98,7 @@ float blocksolve_min_rate(float rate);
 float blocksolve_min_rate_base();   // the explicit value, or the default the automatic scaling starts from
 bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwise a schedule scales the default with its set
 
+int bs_gate_mode();  // fork / join of the block-solve mode's side stream (CU2REC_BS_GATE; 0 under a rocprofv3 counter pass)
 // persistent ordered launches queued so far in this process (CU2REC_ORDERED_PERSISTENT=1; tests check that the form really ran)
 int ordered_persistent_launches();
 // chains EXPECTED to be at least this many blocks of 64 links long run phase 2 in the look-ahead form (0: none, the default;

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-export CU2REC_BS_GATE=0
+export CU2REC_BS_GATE=0  # (the library also takes this by itself when it sees ROCPROF_COUNTER_COLLECTION, which rocprofv3 --pmc exports)
 name=$1; shift
 for ctr in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $ctr | tr ' ' '_')
