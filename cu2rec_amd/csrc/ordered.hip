@@ -549,7 +549,10 @@ template <int J>
 __device__ __forceinline__ void walk_group(const SgdArgs &a, const uint32_t *__restrict__ keys, const uint64_t *__restrict__ vals,
                                            int n_active, const int *__restrict__ item_of_rank, uint32_t item_mask, int n_hot,
                                            int start) {
-    constexpr int D = 4;
+#ifndef CU2REC_WALK_D
+#define CU2REC_WALK_D 4  // user rows a walking group keeps in flight (tuning builds: tools/build_variant.sh)
+#endif
+    constexpr int D = CU2REC_WALK_D;
     const int lane = threadIdx.x & (kGroup - 1);
     const int gshift = threadIdx.x & 48;  // this group's lanes in the wavefront
     if (start >= n_active) return;
