@@ -402,7 +402,7 @@ def blocksolve_affine_blocks(blocks=-1):
 
 def blocksolve_lookahead_blocks(blocks=-1):
     """cu2rec_blocksolve_lookahead_blocks: items expected to collect at least this many 64-update blocks per iteration run phase 2
-    in the look-ahead form (0: off, the default; read when a DeviceCSR's schedule is created)."""
+    in the look-ahead form (default 24: the top chains; 0: off; read when a DeviceCSR's schedule is created)."""
     return lib().cu2rec_blocksolve_lookahead_blocks(int(blocks))
 
 

@@ -273,35 +273,73 @@ __device__ __forceinline__ bool chain_is_lookahead(const BsIteration &it, int ch
 
 // ---- phase 1, look-ahead chains: the cross block N_i = lr L[block i][block i - 1] ---------------------------------------------------
 //     N_i[k][j] = lr (c^(63 + k - j) + a^(63 + k - j) (p_(i,k) . p_(i-1,j)))        (tests/test_blocksolve_algebra.py, lookahead_chain)
-// One workgroup of four wavefronts, one 32 x 32 tile each; both MFMA operands are "lane = row, lane half = half of the columns", so
-// every lane reads its two rows' halves straight from memory into registers -- no LDS.  Rows of links past the block's end are zero.
-__device__ __forceinline__ void gram_cross_block(const SgdArgs &a, const BsIteration &it, int g) {
+// One workgroup of four wavefronts, one 32 x 32 tile each.  Both blocks' 128 rows are gathered into LDS the way phase 1 gathers its
+// own (coalesced 128-byte pieces, every load unconditional at a clamped address) and the MFMA operands are read from there: with every
+// lane reading its two rows straight from memory (the first form) a workgroup took 18 us -- 64 different rows per load instruction.
+// Rows of links past the block's end are zero.  LDS: 2 x 64 rows (the launch asks for that much when there are such workgroups).
+__device__ __forceinline__ void gram_cross_block(const SgdArgs &a, const BsIteration &it, int g, float4 *smem) {
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0 || bd.m == 0 || !chain_is_lookahead(it, bd.chain, it.chains[bd.chain])) return;  // workgroup uniform
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, k = lane & 31, h = lane >> 5;
     const int rt = wave >> 1, ct = wave & 1;  // tile: rows 32 rt .. of this block, columns 32 ct .. of the previous one
-    const int nslots = a.nslots, S0 = (nslots + 1) >> 1;
-    const int xc = static_cast<int>(it.vals[bd.pos0 + min(kH * rt + k, bd.n_valid - 1)] >> 32);
-    const int xp = static_cast<int>(it.vals[bd.pos0 - kB + kH * ct + k] >> 32);
-    const f32x4 *ra = reinterpret_cast<const f32x4 *>(a.P + static_cast<size_t>(xc) * a.ldp);
-    const f32x4 *rb = reinterpret_cast<const f32x4 *>(a.P + static_cast<size_t>(xp) * a.ldp);
+    const int nslots = a.nslots, RS = nslots | 1, S0 = (nslots + 1) >> 1;
+    float4 *tile_c = smem, *tile_p = smem + kB * RS;  // this block's rows | the previous block's
+    {
+        // lane l: link l of this block and of the one before it (all 64 of those exist)
+        const int xc = static_cast<int>(it.vals[bd.pos0 + min(lane, bd.n_valid - 1)] >> 32);
+        const int xp = static_cast<int>(it.vals[bd.pos0 - kB + lane] >> 32);
+        const int rsub = lane >> 3, cs = lane & 7;
+        const int nch = (nslots + 7) >> 3;
+        for (int c0 = 0; c0 < nch; c0 += 2) {
+            float4 vc[2][2], vp[2][2];
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int src_lane = 16 * wave + 8 * pp + rsub;
+                const float4 *sc = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(__shfl(xc, src_lane)) * a.ldp);
+                const float4 *sp = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(__shfl(xp, src_lane)) * a.ldp);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    vc[pp][c] = sc[min(8 * (c0 + c) + cs, nslots - 1)];
+                    vp[pp][c] = sp[min(8 * (c0 + c) + cs, nslots - 1)];
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const int row = 16 * wave + 8 * pp + rsub;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int slot = 8 * (c0 + c) + cs;
+                    if (slot < nslots) {
+                        tile_c[row * RS + slot] = row < bd.n_valid ? vc[pp][c] : zero4();
+                        tile_p[row * RS + slot] = vp[pp][c];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int c = 0; c < S0; c += 4) {
-        f32x4 va[4], vb[4];
+    {
+        const float4 *ra = tile_c + (kH * rt + k) * RS, *rb = tile_p + (kH * ct + k) * RS;
+        for (int c = 0; c < S0; c += 2) {
+            float4 va[2], vb[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // unconditional loads at clamped addresses, zeroed by a select
-            const int slot = h * S0 + c + i;
-            const bool ok = c + i < S0 && slot < nslots;
-            const f32x4 t0 = ra[min(slot, nslots - 1)], t1 = rb[min(slot, nslots - 1)];
-            va[i] = ok ? t0 : f32x4{0.f, 0.f, 0.f, 0.f};
-            vb[i] = ok ? t1 : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 2; ++i) {
+                const int slot = h * S0 + c + i;
+                const bool ok = c + i < S0 && slot < nslots;
+                const float4 t0 = ra[min(slot, nslots - 1)], t1 = rb[min(slot, nslots - 1)];
+                va[i] = ok ? t0 : zero4();
+                vb[i] = ok ? t1 : zero4();
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float pa[4] = {va[i].x, va[i].y, va[i].z, va[i].w}, pb[4] = {vb[i].x, vb[i].y, vb[i].z, vb[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[e], pb[e], acc, 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i][e], vb[i][e], acc, 0, 0, 0);
     }
     const float lr = a.h.lr;
     float *dst = it.Nbuf + static_cast<size_t>(g) * kBsCrossFloats;
@@ -309,10 +347,11 @@ __device__ __forceinline__ void gram_cross_block(const SgdArgs &a, const BsItera
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int i = kH * rt + acc_row(reg, h);  // link i of this block
-        const int d = kB - 1 + i - j;             // 0 .. 126
-        const float v = lr * (it.tables[kTabCpow + d] + it.tables[kTabApow + d] * acc[reg]);
+        const float fd = static_cast<float>(kB - 1 + i - j);  // 0 .. 126
+        const float v = lr * (__builtin_amdgcn_exp2f(fd * it.log2c) + __builtin_amdgcn_exp2f(fd * it.log2a) * acc[reg]);
         dst[i * kB + j] = i < bd.n_valid ? v : 0.f;
     }
+    __syncthreads();  // (the next block of this workgroup's loop writes the tiles again)
 }
 
 // ---- phase 1: the inverse factor of every block --------------------------------------------------------------------
@@ -349,7 +388,7 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
         // wait for and end long before the inversions do
         const BsChainDesc last = it.chains[it.la_ranks - 1];
         const int la_end = min(last.blk0 + (last.len + kB - 1) / kB, it.la_cap);
-        for (int gb = g + it.la_grid; gb < la_end; gb += it.la_grid) gram_cross_block(a, it, gb);
+        for (int gb = g + it.la_grid; gb < la_end; gb += it.la_grid) gram_cross_block(a, it, gb, bs_smem);
         stamp.done(it, 7, 4 * (g + it.la_grid) + wave);
         return;
     }
@@ -2171,8 +2210,9 @@ void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, 
 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
-    const size_t gram_lds = std::max(static_cast<size_t>(kB) * (a.nslots | 1) * 16, static_cast<size_t>(5) * kH * kMS * 4) +
-                            static_cast<size_t>(kGramTabFloats + kB) * 4;
+    size_t gram_lds = std::max(static_cast<size_t>(kB) * (a.nslots | 1) * 16, static_cast<size_t>(5) * kH * kMS * 4) +
+                      static_cast<size_t>(kGramTabFloats + kB) * 4;
+    if (it.la_ranks > 0) gram_lds = std::max(gram_lds, static_cast<size_t>(2) * kB * (a.nslots | 1) * 16);  // (the cross blocks' workgroups: two blocks' rows)
     ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_gram_kernel));
     // `stop`: an event completed by the kernel's own completion signal (hipExtLaunchKernelGGL) -- a hipEventRecord behind the
     // launch is a marker packet of its own and held the NEXT launch of the stream back by 6-7 us (kernel traces, round 3)

@@ -997,7 +997,7 @@ int blocksolve_lookahead_blocks(int blocks) {
     int prev = g_bs_lookahead.load();
     if (prev < 0) {
         const char *env = std::getenv("CU2REC_BLOCKSOLVE_LOOKAHEAD");
-        const int init = env ? std::max(0, std::atoi(env)) : 0;  // opt-in: DESIGN.md section 4, "The look-ahead form"
+        const int init = env ? std::max(0, std::atoi(env)) : 24;  // the top chains only: DESIGN.md section 4, "The look-ahead form"
         g_bs_lookahead.compare_exchange_strong(prev, init);
         prev = g_bs_lookahead.load();
     }

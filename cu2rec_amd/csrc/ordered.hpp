@@ -101,7 +101,7 @@ bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwi
 int bs_gate_mode();  // fork / join of the block-solve mode's side stream (CU2REC_BS_GATE; 0 under a rocprofv3 counter pass)
 // persistent ordered launches queued so far in this process (CU2REC_ORDERED_PERSISTENT=1; tests check that the form really ran)
 int ordered_persistent_launches();
-// chains EXPECTED to be at least this many blocks of 64 links long run phase 2 in the look-ahead form (0: none, the default;
+// chains EXPECTED to be at least this many blocks of 64 links long run phase 2 in the look-ahead form (default 24: the top chains; 0: none;
 // schedules created later); blocks < 0 only queries
 int blocksolve_lookahead_blocks(int blocks);
 // chains of at least this many blocks of 64 links take the affine form (0: none); blocks < 0 only queries

@@ -290,13 +290,14 @@ float cu2rec_blocksolve_min_rate(float rate);
  * set the initial values.  Both return the previous value; blocks < 0 (head: 0) only queries. */
 int cu2rec_blocksolve_affine_blocks(int blocks);
 int cu2rec_blocksolve_affine_head(int blocks);
-/* The longest chains in the look-ahead form (block-solve mode, n_factors <= 116; opt-in, round 4).  Items EXPECTED to collect at
+/* The longest chains in the look-ahead form (block-solve mode, n_factors <= 116; round 4; default: items expected to collect 24 blocks
+ * and more per iteration -- the two or three longest chains of the ML-20M shape: -2.7 % per iteration).  Items EXPECTED to collect at
  * least `blocks` x 64 updates per iteration (the leading popularity ranks): phase 1 also builds, for every block of their chains
  * but the first, the 64 x 64 block of lr L that couples it to the block before it, and phase 2 runs the chain with
  *     e_i = M_i (pre_i - N_i e_(i-1))
  * -- two 64 x 64 matrix-vector products on ONE wavefront as the only dependent work per block, the item row following one block
  * behind on other wavefronts (no meeting points; DESIGN.md section 4, "The look-ahead form").  Same results as the plain form
- * up to float rounding.  Process-wide, read when a schedule is created (like cu2rec_blocksolve_min_rate); 0 = off (default);
+ * up to float rounding.  Process-wide, read when a schedule is created (like cu2rec_blocksolve_min_rate); 0 = off;
  * CU2REC_BLOCKSOLVE_LOOKAHEAD in the environment sets the initial value.  Returns the previous value; blocks < 0 only queries. */
 int cu2rec_blocksolve_lookahead_blocks(int blocks);
 /* Ordered mode on SMALL sets, opt-in (CU2REC_ORDERED_PERSISTENT=1 in the environment): all iterations of a schedule batch in ONE
