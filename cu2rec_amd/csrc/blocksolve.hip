@@ -137,6 +137,7 @@ struct WaveStamp {
     unsigned long long c0 = clock64();  // shader clock (s_memtime): with the 100 MHz wall clock, the frequency the wavefront ran at
 #endif
     __device__ __forceinline__ explicit WaveStamp(const BsIteration &it) : t0(it.stamps ? wall_clock64() : 0) {}
+    __device__ __forceinline__ void restart(const BsIteration &it) { t0 = it.stamps ? wall_clock64() : 0; }  // (a persistent workgroup's next unit)
     __device__ __forceinline__ void fine(const BsIteration &it, int i) {  // -DCU2REC_BS_TRACE=2: the inside of phases 1 and 3
 #if CU2REC_BS_TRACE == 2
         if (it.stamps) {
@@ -204,12 +205,15 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
 }
 
 // ---- plan: one workgroup per iteration of the batch --------------------------------------------------------------
+constexpr int kPlanBins = 1024;  // block numbers told apart in phase 3's order (chains of more blocks: the rest in one bin)
 __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict__ keys, int n_active, int n_hot,
                                                       int item_bits, int max_blocks, const int *__restrict__ item_of_rank,
                                                       int *__restrict__ chain_begin, BsChainDesc *__restrict__ chains,
                                                       BsBlockDesc *__restrict__ blocks, int *__restrict__ walk_begin, size_t stride,
-                                                      int batch_keys) {
+                                                      int batch_keys, int *__restrict__ order) {
     __shared__ int s_part[256];
+    __shared__ int s_bin[kPlanBins];  // blocks per block number (the pipelined phase 3's order: see below)
+    for (int i = threadIdx.x; i < kPlanBins; i += 256) s_bin[i] = 0;
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint32_t *kb = keys + static_cast<size_t>(b) * stride;  // iteration b's share of the sorted keys
     const uint32_t key_base = batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u;  // (keys with / without the iteration above the rank)
@@ -242,10 +246,34 @@ __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict
         const int begin = cb[r], len = cb[r + 1] - begin;
         cd[r] = BsChainDesc{begin, len, off, item_of_rank[r]};
         const int nb = (len + kB - 1) / kB;
-        for (int m = 0; m < nb; ++m) bd[off + m] = BsBlockDesc{begin + kB * m, min(kB, len - kB * m), r, m};
+        for (int m = 0; m < nb; ++m) {
+            bd[off + m] = BsBlockDesc{begin + kB * m, min(kB, len - kB * m), r, m};
+            atomicAdd(&s_bin[min(m, kPlanBins - 1)], 1);
+        }
         off += nb;
     }
     for (int g = s_total + tid; g < max_blocks; g += 256) bd[g] = BsBlockDesc{0, 0, 0, 0};
+    // The order in which the pipelined phase 3 (bs_update_pipe_kernel) takes the blocks: by block number first -- the order in which
+    // the chains, all started together, get through with them.  (Which of two blocks of the same number comes first is left to the
+    // atomics: phase 3's result does not depend on its order.)
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < kPlanBins; ++i) {
+            const int v = s_bin[i];
+            s_bin[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    int *ord = order + static_cast<size_t>(b) * max_blocks;
+    off = s_part[tid];
+    for (int r = r0; r < r1; ++r) {
+        const int nb = (cb[r + 1] - cb[r] + kB - 1) / kB;
+        for (int m = 0; m < nb; ++m) ord[atomicAdd(&s_bin[min(m, kPlanBins - 1)], 1)] = off + m;
+        off += nb;
+    }
+    for (int g = s_total + tid; g < max_blocks; g += 256) ord[g] = g;
 }
 
 // ---- which chains take the affine form (long chains, sequential topology) ---------------------------------------------
@@ -1217,12 +1245,14 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
         for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(q4[p]));
     }
     int ready = 0, ops_prev = 0;
-    if (CONC && w == 0) ready = await_blocks(it, g0, nblk, 0, kDepth + 2, k);
+    // (the pipelined topology runs this instantiation for its announced progress and write-through stores; phase 1 is complete then,
+    // nothing to await)
+    if (CONC && w == 0 && it.concurrent) ready = await_blocks(it, g0, nblk, 0, kDepth + 2, k);
     if (CONC) __syncthreads();  // the gate: the loaders start
     stamp.mark(it, 0);
     __syncthreads();  // block 0 is in the ring
     stamp.mark(it, 1);
-    unsigned long long *progress = it.chain_prog + chain;
+    unsigned long long *progress = it.chain_prog + static_cast<size_t>(chain) * kBsProgWords;
     for (int m = 0; m < n_intervals; ++m) {
         const bool live = m < nblk;  // workgroup uniform
         // Blocks [0, m - 2) have left for phase 3: at the end of block m - 1 every solver wavefront waited for its stores of the
@@ -1345,7 +1375,7 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
         }
         // the records the loaders will ask for after the next barrier: block m + 2 + kDepth (see the loader's loop)
         if (CONC) {
-            if (w == 0) ready = await_blocks(it, g0, nblk, ready, m + 3 + kDepth, k);
+            if (w == 0 && it.concurrent) ready = await_blocks(it, g0, nblk, ready, m + 3 + kDepth, k);
             wait_all_but(ops_now + ops_prev);  // (never more than this wavefront really issued in the two blocks: see stores_per_block)
             ops_prev = ops_now;
         }
@@ -1507,7 +1537,7 @@ __device__ __forceinline__ void la_wait2(unsigned *sy, int word, unsigned target
 #endif
 }
 
-template <int NSM>
+template <int NSM, bool PIPE>
 __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIteration &it, float4 *smem, WaveStamp &stamp, int chain,
                                                 const BsChainDesc &cd) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1698,6 +1728,16 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
         __syncthreads();
         __builtin_amdgcn_s_setprio(2);
         unsigned long long wt[1] = {0};
+        // (pipelined topology: the start rows leave with write-through stores the compiler does not count, and this wavefront announces,
+        // a block late, how many blocks' worth of its stores are complete -- word 1 + c of the chain's progress record)
+        int my_stores = 0;
+#pragma unroll
+        for (int pp = 0; pp < NPW; ++pp) my_stores += 8 * (2 * pp + c) < nslots ? 1 : 0;
+        unsigned long long *progress = it.chain_prog + static_cast<size_t>(chain) * kBsProgWords + 1 + c;
+        if (PIPE) {
+#pragma unroll
+            for (int pp = 0; pp < NPW; ++pp) asm volatile("" ::"v"(q4[pp]));  // (the prologue's loads consumed in front of the loop)
+        }
         for (int i = 0; i < nblk; ++i) {
             const int n = min(kB, len - kB * i);
             const float adel_n = tab[kTabAdel + n];
@@ -1718,7 +1758,14 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
             for (int pp = 0; pp < NPW; ++pp) {
                 const int slot = 8 * (2 * pp + c) + sl;
                 const bool ok = slot < nslots;
-                if (ok && kg == 0) *reinterpret_cast<f32x4 *>(qdst + 4 * slot) = q4[pp];  // the row in front of block i: phase 3's
+                // the row in front of block i: phase 3's
+                if (PIPE) {
+                    if (8 * (2 * pp + c) < nslots) {  // wavefront uniform: the instruction is issued exactly when the pass holds a slot
+                        if (ok && kg == 0) store_through(qdst + 4 * slot, q4[pp]);
+                    }
+                } else if (ok && kg == 0) {
+                    *reinterpret_cast<f32x4 *>(qdst + 4 * slot) = q4[pp];
+                }
                 f32x2 ulo = dup2(0.f), uhi = dup2(0.f);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -1739,6 +1786,16 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
                 if (ok && kg == 0) *reinterpret_cast<f32x4 *>(qbuf + ((i + 1) & 1) * kLaQ4 + slot) = q4[pp];
             }
             la_post(sy, kSyC0 + c, static_cast<unsigned>(i + 1));
+            // everything older than the stores of the two youngest blocks (and the announcement between them) is complete: blocks
+            // [0, i - 1) have left.  (Two blocks behind: the latency of a write-through store stays off the chain.)
+            if (PIPE && i > 1) {
+                wait_all_but(2 * my_stores + 1);
+                if (lane == 0) st_agent_u64(progress, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(i - 1));
+            }
+        }
+        if (PIPE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) st_agent_u64(progress, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(nblk));
         }
         if (kg == 0) {
             f32x4 *qd = reinterpret_cast<f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
@@ -1791,6 +1848,7 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
         la_post(sy, kSyR, static_cast<unsigned>(i + 1));  // (the slot's reads are issued: LDS serves a wavefront in order)
     };
     take_record(0);
+    unsigned long long *eprog = it.chain_prog + static_cast<size_t>(chain) * kBsProgWords;
     for (int i = 0; i < nblk; ++i) {
         const int n = min(kB, len - kB * i);
         // t0 = N_i e_(i-1): this lane's row of the cross block against the errors of the block before (all 16 broadcast reads in
@@ -1839,7 +1897,7 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
         ebl[(i & 1) * kB + k] = e;
         wbuf[(i & 1) * kB + k] = k < n ? lr * tab[kTabApow + back] * e : 0.f;
         la_post(sy, kSyE, static_cast<unsigned>(i + 1));
-        it.ebuf[static_cast<size_t>(g0 + i) * kB + k] = e;
+        if (PIPE) store_through(it.ebuf + static_cast<size_t>(g0 + i) * kB + k, e); else it.ebuf[static_cast<size_t>(g0 + i) * kB + k] = e;
         if (i + 1 < nblk) take_record(i + 1);  // wavefront uniform
         // the item bias behind block i
         const float bs = row_sum16(k < n ? lr * tab[kTabCpow + back] * e : 0.f);
@@ -1847,6 +1905,14 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
         const float b_next = (b_cur - cdel_n * b_cur) + ((lane_value(bs, 0) + lane_value(bs, 16)) + (lane_value(bs, 32) + lane_value(bs, 48)));
         b_prev = b_cur;
         b_cur = b_next;
+        if (PIPE && i > 1) {  // the errors of blocks [0, i - 1) are in memory (pending at most: e, announcement, e): announce them
+            asm volatile("s_waitcnt vmcnt(3)");
+            if (k == 0) st_agent_u64(eprog, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(i - 1));
+        }
+    }
+    if (PIPE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (k == 0) st_agent_u64(eprog, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(nblk));
     }
     stamp.span(1, wt[0]);
     stamp.span(2, wt[1]);
@@ -1859,11 +1925,32 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
 // chains come first and get a workgroup each): phase 1 runs at the same time and needs CUs of its own -- a chain's workgroup (2 x ~220
 // registers per SIMD, 80-160 KB of LDS) leaves no room for a phase-1 workgroup beside it, and chains waiting on every CU for
 // records nobody can produce would be a deadlock.  Sequential topology: one workgroup per chain.
-template <int SW, bool CONC>
+// The join with the side stream (and, pipelined topology, with phase 3): one thread of an extra workgroup in the LAST launch of the
+// iteration on the main stream.  It ends when the signal kernel queued behind this iteration's side kernel has run -- i.e. that kernel
+// is complete, its rows in memory -- so that the next iteration's phase 1, queued behind this launch, needs no event (a wait on one
+// costs the stream 2.5 us per iteration).  (The side kernel's workgroups counting THEMSELVES through, each behind an agent-scope
+// release of its rows, was tried in round 4: 9350 L2 write-backs per launch, the side kernel took 292 us instead of 46.)
+// This wait guards DATA -- the next phase 1 reads rows the side kernel and phase 3 write -- so it gives up only when the GPU must be
+// taken for wedged: 15 x the bound of the other waits, 30 s by default; then the status word is set and the call reports it.
+__device__ __forceinline__ void await_iteration_end(const BsIteration &it) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned polls = 0;
+    while ((it.side_seq && ld_agent(it.side_seq) < it.side_target) || (it.pipe && ld_agent(it.pipe_done) < it.pipe_target)) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((++polls & 63u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > 15ull * it.wait_ticks)) {
+            __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
+// TOPO: 0 sequential, 1 concurrent, 2 pipelined (the sequential grid; the chains announce their progress block by block for the phase 3
+// that runs beside them, and one more workgroup ends the launch when that phase 3 and the side stream are through).
+template <int SW, int TOPO>
 __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it) {
     extern __shared__ float4 bs_smem[];
     WaveStamp stamp(it);
-    if (CONC) {
+    if (TOPO == 1) {
         if (threadIdx.x == 0) __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // "I hold my CU"
         for (int chain = blockIdx.x; chain < it.n_hot; chain += gridDim.x) solve_chain<SW, true>(a, it, bs_smem, stamp, chain, it.chains[chain]);
     } else if (static_cast<int>(blockIdx.x) < it.n_hot) {
@@ -1875,13 +1962,22 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
         // out of the wider instantiations
         if constexpr (SW <= 8) {
             if (chain_is_lookahead(it, chain, cd)) {  // workgroup uniform
-                chain_lookahead<(4 * SW < kLaMaxSlots ? 4 * SW : kLaMaxSlots)>(a, it, bs_smem, stamp, chain, cd);
+                chain_lookahead<(4 * SW < kLaMaxSlots ? 4 * SW : kLaMaxSlots), TOPO == 2>(a, it, bs_smem, stamp, chain, cd);
                 return;
             }
         }
-        bool head_only = false;
-        if constexpr (SW <= 8) head_only = cd.len > 0 && chain_is_affine(it, chain);  // workgroup uniform
-        solve_chain<SW, false>(a, it, bs_smem, stamp, chain, BsChainDesc{cd.begin, head_only ? it.aff_head * kB : cd.len, cd.blk0, cd.item}, head_only);
+        if constexpr (TOPO == 2) {
+            solve_chain<SW, true>(a, it, bs_smem, stamp, chain, cd);
+        } else {
+            bool head_only = false;
+            if constexpr (SW <= 8) head_only = cd.len > 0 && chain_is_affine(it, chain);  // workgroup uniform
+            solve_chain<SW, false>(a, it, bs_smem, stamp, chain, BsChainDesc{cd.begin, head_only ? it.aff_head * kB : cd.len, cd.blk0, cd.item}, head_only);
+        }
+    } else if (TOPO == 2) {
+        if (threadIdx.x == 0) {  // (blockIdx.x == n_hot: the join, see await_iteration_end)
+            __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            await_iteration_end(it);
+        }
     } else {
         const int g = static_cast<int>(blockIdx.x) - it.n_hot;
         if constexpr (SW <= 8) {
@@ -1899,80 +1995,53 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
 }
 
 // ---- phase 3: the user side of every hot block ---------------------------------------------------------------------
-// One wavefront per (block, 32 columns).  T[k][j] = lr a^(k-1-j) e_j (j < k), 64 x 64 lower triangular in three 32 x 32
-// tiles, is the A operand, the block's user rows the B operand, the accumulators start from a^k q0: the result is the
-// item row as link k saw it.  The 64 x 32 piece of P comes in with eight 16-byte loads per lane into LDS, is both the B
-// operand and the old value of the update, takes the new values and leaves with eight 16-byte stores per lane; errors,
-// user ids and the powers of a are read from LDS as well (a lane-dependent readlane would turn into branches).
-constexpr int kUpdStride = 36;                               // floats per tile row: 16-byte rows, 2-way conflicts at most
-constexpr int kUpdWaveFloats = kB * kUpdStride + 3 * kB;     // tile | e | user ids | partial errors (affine blocks)
-constexpr int kUpdPowPad = 32;                               // a^d, d in [-32, 64), zero below 0
-__host__ __device__ inline size_t update_lds_bytes(int ntiles) { return (static_cast<size_t>(ntiles) * kUpdWaveFloats + kUpdPowPad + kB) * 4; }
+// One wavefront per (block, 64 columns), lane = column.  The wavefront holds its 64 x 64 piece of the block's user rows in registers
+// (one 256-byte row segment per load instruction, user id and error of link k broadcast from lane k) and walks down the links with
+// the reference's own recurrence (mf_sequential.cu:133-134), the item row as link k saw it carried in one register:
+//     p_k <- p_k + lr (e_k q - P_reg p_k),   q <- q + lr (e_k p_k - Q_reg q)        (p_k on the right: the old value)
+// 64 dependent steps of a few VALU instructions (~0.4 us), no LDS, no staging.  (Rounds 2-3 built the rows "as link k saw them"
+// as a triangular 64 x 64 product on the MFMA pipe: 48 fp32 MFMA instructions and ~200 LDS reads per 32 columns, 3 us of a wavefront's
+// 9 -- and the kernel's duration IS one wavefront's latency, every block's workgroup being resident at once.)
+constexpr int kUpdMaxWaves = (4 * kBsMaxSlots + 63) / 64;
 
-// One workgroup per block, one wavefront per 32 columns.
-__global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration it, int ntiles) {
-    extern __shared__ float4 bs_smem[];
-    float *upd_smem = reinterpret_cast<float *>(bs_smem);
+__device__ __forceinline__ void update_block(const SgdArgs &a, const BsIteration &it, int g, int nwaves, float *parts, WaveStamp &stamp) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *pw = upd_smem + ntiles * kUpdWaveFloats;
-    const int g = blockIdx.x, ct = wave;
-    WaveStamp stamp(it);
-    if (g == it.max_blocks) {
-        // The extra workgroup of the launch (side_seq set): the join with the side stream.  It ends when the signal kernel queued
-        // behind this iteration's side kernel has run -- i.e. that kernel is complete, its rows in memory -- so that the next
-        // iteration's phase 1, queued behind this launch, needs no event (a wait on one costs the stream 2.5 us per iteration).
-        if (threadIdx.x == 0) {
-            const unsigned long long t0 = wall_clock64();
-            unsigned polls = 0;
-            // (this wait guards DATA -- the next phase 1 reads rows the side kernel writes -- so it gives up only when the GPU must be
-            // taken for wedged: 15 x the bound of the other waits, 30 s by default; then the status word is set and the call reports it)
-            while (ld_agent(it.side_seq) < it.side_target) {
-                __builtin_amdgcn_s_sleep(16);
-                if ((++polls & 63u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > 15ull * it.wait_ticks)) {
-                    __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        return;
-    }
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) return;  // workgroup uniform
     const bool affine = block_is_affine(it, bd);
-    for (int i = threadIdx.x; i < kUpdPowPad + kB; i += blockDim.x) pw[i] = i < kUpdPowPad ? 0.f : it.tables[kTabApow + i - kUpdPowPad];
-    float *tile = upd_smem + wave * kUpdWaveFloats;
-    float *se = tile + kB * kUpdStride;
-    int *sx = reinterpret_cast<int *>(se + kB);
-    const int c = lane & 31, h = lane >> 5;
     const bool mine = lane < bd.n_valid;  // lane l: link l
     // links past the end of a short block: the last link's row (finite, loaded, never stored) with e = 0
     const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
     const int x = static_cast<int>(val >> 32);
     const float lr = a.h.lr;
     const int ncols = 4 * a.nslots;
-    const int col = 32 * ct + c, colc = min(col, ncols - 1);
+    const int col = 64 * wave + lane, colc = min(col, ncols - 1);
     // The chain's workgroup (bs_solve_kernel, ANOTHER launch running beside this one) announces how many of its blocks have left
-    // for phase 3: errors and start row of block m are there once the count has passed m.  Bounded wait, then an acquire (the
-    // L1 of this CU may hold lines of ebuf / qstart that shared a cache line with something read earlier).
-    if (it.concurrent && threadIdx.x == 0 && !(it.dbg & 8)) {
-        const unsigned long long *progress = it.chain_prog + bd.chain;
-        const unsigned long long want = static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(bd.m + 1);
-        const unsigned long long t0 = wall_clock64();
-        unsigned polls = 0;
-        for (;;) {
-            const unsigned long long v = ld_agent(progress);
-            if ((v >> 32) == it.epoch && v >= want) break;
-            __builtin_amdgcn_s_sleep(48);  // ~1.3 us: hundreds of workgroups poll a few dozen words
-            if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
-                __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+    // for phase 3: errors and start row of block m are there once the count has passed m (a look-ahead chain: the counts of the
+    // three wavefronts that store them).  Bounded wait; what the chain stored is then read with loads that are never served from a
+    // cache of this side (sc1: this XCD's L2 may still hold the block's lines of the iteration before).
+    const bool waits = (it.concurrent || it.pipe) && !(it.dbg & 8);  // workgroup uniform
+    if (waits) {
+        if (wave == 0) {
+            const int nwords = it.pipe && chain_is_lookahead(it, bd.chain, it.chains[bd.chain]) ? 3 : 1;
+            const unsigned long long *progress = it.chain_prog + static_cast<size_t>(bd.chain) * kBsProgWords + min(lane, nwords - 1);
+            const unsigned long long want = static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(bd.m + 1);
+            const unsigned long long t0 = wall_clock64();
+            unsigned polls = 0;
+            for (;;) {
+                const unsigned long long v = ld_agent(progress);
+                if (__all((v >> 32) == it.epoch && v >= want)) break;
+                if (it.pipe) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(48);  // (concurrent: hundreds of workgroups poll a few dozen words)
+                if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
+                    if (lane == 0) __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
-    __syncthreads();  // (also: the table of powers)
-    const float qs = it.qstart[static_cast<size_t>(g) * a.ldq + colc];
+    const float qs = waits ? __uint_as_float(ld_agent(reinterpret_cast<const unsigned *>(it.qstart + static_cast<size_t>(g) * a.ldq + colc)))
+                           : it.qstart[static_cast<size_t>(g) * a.ldq + colc];
     float e_all;
     if (affine) {
         // e = -W (s0, -1): lane = link, this wavefront's share of the 16-byte columns, the shares summed through LDS
@@ -1981,7 +2050,7 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
         const float4 *q4 = reinterpret_cast<const float4 *>(it.qstart + static_cast<size_t>(g) * a.ldq);
         const float b0 = it.bstart[g];
         float part = 0.f;
-        for (int cc = ct; cc <= nslots; cc += ntiles) {
+        for (int cc = wave; cc <= nslots; cc += nwaves) {
             const float4 w4 = wrow[cc];
             const float4 qv = q4[min(cc, nslots - 1)];
             const float4 sv = cc < nslots ? qv : make_float4(b0, -1.f, 0.f, 0.f);
@@ -1990,97 +2059,78 @@ __global__ __launch_bounds__(512) void bs_update_kernel(SgdArgs a, BsIteration i
             part = __builtin_fmaf(w4.z, sv.z, part);
             part = __builtin_fmaf(w4.w, sv.w, part);
         }
-        float *parts = upd_smem + ct * kUpdWaveFloats + kB * kUpdStride + 2 * kB;
-        parts[lane] = part;
+        parts[wave * kB + lane] = part;
         __syncthreads();
         float sum = 0.f;
-        for (int w = 0; w < ntiles; ++w) sum += upd_smem[w * kUpdWaveFloats + kB * kUpdStride + 2 * kB + lane];
+        for (int w = 0; w < nwaves; ++w) sum += parts[w * kB + lane];
         e_all = -sum;
-        if (ct == 0) it.ebuf[static_cast<size_t>(g) * kB + lane] = mine ? e_all : 0.f;  // for the record (tests read the errors back)
+        if (wave == 0) it.ebuf[static_cast<size_t>(g) * kB + lane] = mine ? e_all : 0.f;  // for the record (tests read the errors back)
     } else {
-        e_all = it.ebuf[static_cast<size_t>(g) * kB + lane];
+        e_all = waits ? __uint_as_float(ld_agent(reinterpret_cast<const unsigned *>(it.ebuf + static_cast<size_t>(g) * kB + lane)))
+                      : it.ebuf[static_cast<size_t>(g) * kB + lane];
     }
     const float e = mine ? e_all : 0.f;
-    se[lane] = e;
-    sx[lane] = x;
-    __builtin_amdgcn_wave_barrier();
-    stamp.fine(it, 0);  // errors, user ids, start row
-    const int rsub = lane >> 3, cs = lane & 7;
-    const int slot = 8 * ct + cs, slotc = min(slot, a.nslots - 1);
-    {
-        float4 v[8];
+    stamp.fine(it, 0);  // user ids
+    float p[kB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            v[i] = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(sx[8 * i + rsub]) * a.ldp)[slotc];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4 *>(tile + (8 * i + rsub) * kUpdStride + 4 * cs) = v[i];
+    for (int k = 0; k < kB; ++k) {
+        const int xk = __builtin_amdgcn_readlane(x, k);
+        p[k] = a.P[static_cast<size_t>(xk) * a.ldp + colc];
     }
-    __builtin_amdgcn_wave_barrier();
-    stamp.fine(it, 1);  // the block's rows in LDS
-    // operands of step s: the contraction index is 16 h + s inside a 32-link half
-    float t00[16], t10[16], t11[16], b0[16], b1[16];
+    float q = qs;
+    const float p_reg = a.h.p_reg, q_reg = a.h.q_reg;
+    stamp.fine(it, 1);  // loads issued; errors, start row
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        const float4 e0 = *reinterpret_cast<const float4 *>(se + 16 * h + 4 * s4);
-        const float4 e1 = *reinterpret_cast<const float4 *>(se + kH + 16 * h + 4 * s4);
-        const float e0v[4] = {e0.x, e0.y, e0.z, e0.w}, e1v[4] = {e1.x, e1.y, e1.z, e1.w};
+    for (int k = 0; k < kB; ++k) {
+        const float ek = lane_value(e, k);
+        const float pk = p[k];
+        p[k] = pk + lr * (ek * q - p_reg * pk);  // mf_sequential.cu:133-134
+        q = q + lr * (ek * pk - q_reg * q);
+    }
+    // (the stores in a sequence of their own behind the walk: interleaved with it -- what the compiler makes of the two unrolled loops --
+    // every step's wait for its row also waited for stores issued before it, 5 us per wavefront)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int s = 4 * s4 + i, j = 16 * h + s;
-            const float near = lr * pw[kUpdPowPad + c - 1 - j];      // a^(k-1-j) inside a diagonal tile, 0 for j >= k
-            t00[s] = near * e0v[i];                                  // row k = c
-            t11[s] = near * e1v[i];                                  // row 32 + c, column 32 + j
-            t10[s] = lr * pw[kUpdPowPad + kH + c - 1 - j] * e0v[i];  // row 32 + c, column j
-            b0[s] = tile[j * kUpdStride + c];
-            b1[s] = tile[(kH + j) * kUpdStride + c];
+    for (int k = 0; k < kB; ++k) asm volatile("" : "+v"(p[k]));  // (the values exist HERE: no sinking of the walk into the stores)
+    __builtin_amdgcn_sched_barrier(0);
+    stamp.fine(it, 2);  // new rows
+    if (col < ncols) {
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+            if (k < bd.n_valid) a.P[static_cast<size_t>(__builtin_amdgcn_readlane(x, k)) * a.ldp + col] = p[k];  // wavefront uniform
         }
     }
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int kk = acc_row(reg, h);
-        acc0[reg] = qs * pw[kUpdPowPad + kk];
-        acc1[reg] = qs * pw[kUpdPowPad + kH + kk];
-    }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(t00[s], b0[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(t10[s], b0[s], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(t11[s], b1[s], acc1, 0, 0, 0);
-    stamp.fine(it, 2);  // products issued
-    __builtin_amdgcn_wave_barrier();  // every B operand has been read: the tile takes the new values
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float4 ea = *reinterpret_cast<const float4 *>(se + 8 * t + 4 * h);
-        const float4 eb = *reinterpret_cast<const float4 *>(se + kH + 8 * t + 4 * h);
-        const float eav[4] = {ea.x, ea.y, ea.z, ea.w}, ebv[4] = {eb.x, eb.y, eb.z, eb.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int reg = 4 * t + i, kk = acc_row(reg, h);
-            float *p0 = tile + kk * kUpdStride + c, *p1 = tile + (kH + kk) * kUpdStride + c;
-            const float o0 = *p0, o1 = *p1;
-            *p0 = o0 + lr * (eav[i] * acc0[reg] - a.h.p_reg * o0);  // mf_sequential.cu:133-134
-            *p1 = o1 + lr * (ebv[i] * acc1[reg] - a.h.p_reg * o1);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    stamp.fine(it, 3);  // new rows in LDS
-    if (slot < a.nslots) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = 8 * i + rsub;
-            if (row < bd.n_valid)
-                reinterpret_cast<float4 *>(a.P + static_cast<size_t>(sx[row]) * a.ldp)[slot] =
-                    *reinterpret_cast<const float4 *>(tile + row * kUpdStride + 4 * cs);
-        }
-    }
-    if (ct == 0 && mine) {
+    if (wave == 0 && mine) {
         const float ub = a.user_bias[x];
         a.user_bias[x] = ub + lr * (e - a.h.ub_reg * ub);  // mf_sequential.cu:140
     }
-    stamp.done(it, 4, g * ntiles + ct);
+    stamp.done(it, 4, g * nwaves + wave);
+}
+
+// One workgroup per block (sequential and concurrent topologies).
+__global__ __launch_bounds__(64 * kUpdMaxWaves) void bs_update_kernel(SgdArgs a, BsIteration it, int nwaves) {
+    __shared__ float parts[kUpdMaxWaves * kB];
+    const int g = blockIdx.x;
+    WaveStamp stamp(it);
+    if (g == it.max_blocks) {  // the extra workgroup of the launch (side_seq set)
+        if (threadIdx.x == 0) await_iteration_end(it);
+        return;
+    }
+    update_block(a, it, g, nwaves, parts, stamp);
+}
+
+// Pipelined topology: a grid of persistent workgroups beside phase 2, block order[j] to workgroup j mod grid.  Every wait is bounded
+// and every workgroup visits a fixed list of blocks: the grid drains whatever phase 2 does.
+__global__ __launch_bounds__(64 * kUpdMaxWaves) void bs_update_pipe_kernel(SgdArgs a, BsIteration it, int nwaves) {
+    __shared__ float parts[kUpdMaxWaves * kB];
+    WaveStamp stamp(it);
+    for (int j = blockIdx.x; j < it.max_blocks; j += gridDim.x) {
+        stamp.restart(it);
+        update_block(a, it, it.order[j], nwaves, parts, stamp);
+    }
+    // this workgroup's rows are on their way: the count is released behind them (the waiting workgroup of phase 2's launch reads it)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (every wavefront's stores complete in front of the barrier)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(it.pipe_done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int SW>
@@ -2089,11 +2139,18 @@ void launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
                           it.aff_min_blocks > 0 ? std::max(affine_lds_bytes(a.nslots), affine_build_lds_bytes(a.nslots)) : static_cast<size_t>(0));
     if (it.la_ranks > 0) lds = std::max(lds, la_lds_bytes(a.nslots));
     if (it.concurrent) {
-        ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, true>));
-        hipLaunchKernelGGL((bs_solve_kernel<SW, true>), dim3(bs_solve_grid(it.n_hot)), dim3(512), lds, stream, a, it);
+        ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, 1>));
+        hipLaunchKernelGGL((bs_solve_kernel<SW, 1>), dim3(bs_solve_grid(it.n_hot)), dim3(512), lds, stream, a, it);
+    } else if (it.pipe) {
+        if constexpr (SW <= 8) {  // (the wider rows' chains spill in the form that announces its progress: ordered.hip does not ask for it)
+            ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, 2>));
+            hipLaunchKernelGGL((bs_solve_kernel<SW, 2>), dim3(it.n_hot + 1), dim3(512), lds, stream, a, it);
+        } else {
+            fail(CU2REC_EINVAL, "the pipelined topology is compiled for rows of at most 32 float4 slots");
+        }
     } else {
-        ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, false>));
-        hipLaunchKernelGGL((bs_solve_kernel<SW, false>), dim3(it.n_hot + (it.aff_min_blocks > 0 ? it.aff_cap + it.aff_tails : 0)), dim3(512), lds, stream, a, it);
+        ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, 0>));
+        hipLaunchKernelGGL((bs_solve_kernel<SW, 0>), dim3(it.n_hot + (it.aff_min_blocks > 0 ? it.aff_cap + it.aff_tails : 0)), dim3(512), lds, stream, a, it);
     }
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
@@ -2203,9 +2260,9 @@ void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream) {
 
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
                     const int *item_of_rank, int *chain_begin, BsChainDesc *chains, BsBlockDesc *blocks, int *walk_begin,
-                    hipStream_t stream, size_t stride, bool batch_keys) {
+                    hipStream_t stream, size_t stride, bool batch_keys, int *order) {
     hipLaunchKernelGGL(bs_plan_kernel, dim3(n_batch), dim3(256), 0, stream, keys, n_active, n_hot, item_bits, max_blocks,
-                       item_of_rank, chain_begin, chains, blocks, walk_begin, stride, batch_keys ? 1 : 0);
+                       item_of_rank, chain_begin, chains, blocks, walk_begin, stride, batch_keys ? 1 : 0, order);
 }
 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop) {
@@ -2274,11 +2331,17 @@ void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream
     else fail(CU2REC_EUNSUPPORTED, "block-solve mode is compiled for n_factors <= 256");
 }
 
+void bs_launch_update_pipe(const SgdArgs &a, const BsIteration &it, int grid, hipStream_t stream) {
+    if (it.n_hot <= 0 || it.max_blocks <= 0 || grid <= 0) return;
+    const int nwaves = (4 * a.nslots + 63) / 64;
+    hipLaunchKernelGGL(bs_update_pipe_kernel, dim3(grid), dim3(64 * nwaves), 0, stream, a, it, nwaves);
+    CU2REC_HIP(hipGetLastError());
+}
+
 void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
-    const int ntiles = (4 * a.nslots + 31) / 32;
-    ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_update_kernel));
-    hipLaunchKernelGGL(bs_update_kernel, dim3(it.max_blocks + (it.side_seq ? 1 : 0)), dim3(64 * ntiles), update_lds_bytes(ntiles), stream, a, it, ntiles);
+    const int nwaves = (4 * a.nslots + 63) / 64;
+    hipLaunchKernelGGL(bs_update_kernel, dim3(it.max_blocks + (it.side_seq ? 1 : 0)), dim3(64 * nwaves), 0, stream, a, it, nwaves);
     CU2REC_HIP(hipGetLastError());
 }
 

@@ -17,6 +17,7 @@ constexpr int kBsTableFloats = 4 * kBsTableStride;
 constexpr int kBsFactorFloats = 3 * 32 * 32;        // inverse factor of a block: tiles M11, M21, M22 (32 x 32 each, row major)
 constexpr int kBsRecFloats = kBsFactorFloats + kBsLinks;  // a block's record from phase 1: the factor, then r - gb - ub per link
 constexpr int kBsCrossFloats = kBsLinks * kBsLinks;  // look-ahead chains: the 64 x 64 block of lr L that couples a block (rows) to the one before it (columns)
+constexpr int kBsProgWords = 4;                     // 8-byte words of a chain's progress record (32 bytes)
 constexpr int kBsMaxSlots = 63;                     // float4 slots per row the solver has LDS for (n_factors <= 252)
 
 struct BsBlockDesc {  // up to 64 consecutive links of one hot chain
@@ -74,15 +75,24 @@ struct BsIteration {
                                       // below; 0 (default): they are queued one behind the other and none of this is used
     unsigned epoch;                   // of this iteration (never 0)
     unsigned *gram_flag;              // [max_blocks]  == epoch: phase 1 has written block g's record (write-through)
-    unsigned long long *chain_prog;   // [n_hot]       epoch << 32 | blocks of the chain whose errors / start rows have left phase 2
+    unsigned long long *chain_prog;   // [n_hot][kBsProgWords]  epoch << 32 | blocks of the chain whose errors / start rows have left phase 2 (a look-ahead
+                                      //               chain: one word for each of the three wavefronts that store them)
     unsigned *status;                 // [1]           set by a wait that gave up (bounded spins); the host reports it
     // Phase 3's workgroups WAIT on the device, so phase 2's must hold their CUs before phase 3 is dispatched (a CU filled with
     // waiting phase-3 workgroups has no room for the chain they wait for).  Every phase-2 workgroup counts itself in when
     // it starts; the last workgroup of phase 1's grid leaves only when the count has reached this iteration's target --
     // and phase 3 is queued behind phase 1 on the same stream.
+    // Pipelined topology (default on a device that runs the streams side by side, ordered.hip): phase 1, then phase 2 with phase 3 BESIDE it --
+    // a launch of `pipe_grid` persistent workgroups on another stream that take the blocks in `order` and wait, block by block, for the
+    // chains' progress words.  Phase 2's launch has one more workgroup that ends when phase 3's workgroups (pipe_done) and the side
+    // stream's kernel (side_seq) are through: the next phase 1 follows it without an event.
+    int pipe;
+    const int *order;                    // [max_blocks] block indices, by block number inside the chain first
+    unsigned long long *pipe_done;       // [1]  phase-3 workgroups through, over all iterations so far
+    unsigned long long pipe_target;      //      ... including all of this iteration's
     unsigned long long *solve_started;   // [1]  phase-2 workgroups started, over all iterations so far
     const unsigned long long *side_seq;  // (or null) the word a signal kernel behind the side kernel sets to the iteration's number ...
-    unsigned long long side_target;      // ... and the number phase 3's extra workgroup waits for: the join without an event
+    unsigned long long side_target;      // ... and the number the extra workgroup of the main stream's last launch waits for: the join without an event
     unsigned long long *gram_done;       // [32 x 16]  phase-1 workgroups through (32 shards, 128 bytes apart), over all iterations so far (or null): what the side
                                          //      stream's gate kernel waits for (bs_launch_gate) -- timing only, no data behind it
     unsigned long long started_target;   //      ... including all of this iteration's
@@ -102,6 +112,7 @@ void bs_get_stamps(unsigned long long **buf, int *cap);
 unsigned long long bs_wait_ticks();
 bool bs_supported(int nslots);
 bool bs_lookahead_supported(int nslots);  // rows of at most 31 float4 slots: the look-ahead form's rings fit the LDS
+inline bool bs_pipe_supported(int nslots) { return nslots <= 32; }  // the pipelined topology: n_factors <= 128
 int bs_compute_units();       // of the current device
 int bs_solve_grid(int n_hot);  // workgroups of phase 2: one per chain, at most half the CUs of the current device
 // bounded device-side waits report through one status word per device: its address, an asynchronous refresh of the host copy
@@ -122,7 +133,7 @@ void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream);
 // one workgroup per iteration of the batch: chain and block descriptors
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
                     const int *item_of_rank, int *chain_begin, BsChainDesc *chains, BsBlockDesc *blocks, int *walk_begin,
-                    hipStream_t stream, size_t stride, bool batch_keys);
+                    hipStream_t stream, size_t stride, bool batch_keys, int *order);
 // the three phases of one iteration's hot chains: three launches that may run at the same time on three streams (phase 2 waits
 // for phase 1's records block by block, phase 3 for phase 2's progress chain by chain, through the words above)
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop = nullptr);
@@ -133,6 +144,8 @@ void bs_launch_signal(unsigned long long *word, unsigned long long value, hipStr
 void bs_launch_gate(const unsigned long long *count, unsigned long long target, const unsigned long long *started,
                     unsigned long long started_target, hipStream_t stream);
 void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream);
+// the pipelined topology's phase 3: `grid` persistent workgroups (the caller queues it behind a gate: phase 2's workgroups hold their CUs)
+void bs_launch_update_pipe(const SgdArgs &a, const BsIteration &it, int grid, hipStream_t stream);
 
 
 

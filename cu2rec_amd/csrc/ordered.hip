@@ -911,6 +911,7 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         walk_begin[slot].allocate(max_batch);
         bs_chains[slot].allocate(static_cast<size_t>(max_batch) * std::max(n_hot_bs, 1));
         bs_blocks[slot].allocate(static_cast<size_t>(max_batch) * max_blocks);
+        bs_order[slot].allocate(static_cast<size_t>(max_batch) * std::max(max_blocks, 1));
     }
     {
         // The next batch's schedule is built beside the iterations that consume this batch's, on a stream of the lowest priority
@@ -930,8 +931,10 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         ebuf.allocate(static_cast<size_t>(max_blocks) * kBsLinks);
         gram_flag.allocate(max_blocks);
         gram_flag.zero();  // epochs start at 1
-        chain_prog.allocate(n_hot_bs);
+        chain_prog.allocate(static_cast<size_t>(n_hot_bs) * kBsProgWords);
         chain_prog.zero();
+        pipe_done.allocate(16);
+        pipe_done.zero();
         solve_started.allocate(16);
         solve_started.zero();
         gram_done.allocate(32 * 16);
@@ -991,6 +994,17 @@ int blocksolve_affine_blocks(int blocks) {
 
 namespace {
 std::atomic<int> g_bs_lookahead{-1};  // -1: not yet initialised from the environment
+}
+
+// Workgroups of the pipelined phase 3 (bs_update_pipe_kernel): persistent, so few enough to leave the side kernel its room, and enough
+// to keep up with the chains (a block takes a workgroup a few microseconds; the chains together deliver a few dozen blocks per microsecond).
+int blocksolve_pipe_grid(int set) {
+    static int grid = [] {
+        const char *e = std::getenv("CU2REC_BLOCKSOLVE_PIPE_GRID");
+        return e && std::atoi(e) > 0 ? std::atoi(e) : 0;
+    }();
+    if (set > 0) grid = set;
+    return grid > 0 ? grid : 2 * bs_compute_units();
 }
 
 int blocksolve_lookahead_blocks(int blocks) {
@@ -1128,7 +1142,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             CU2REC_HIP(hipGetLastError());
             if (blocksolve)
                 bs_launch_plan(ready[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
-                               bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, false);
+                               bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, false, bs_order[slot].ptr);
             CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
             slot_used[slot] = true;
             return;
@@ -1158,7 +1172,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         CU2REC_HIP(hipGetLastError());
         if (blocksolve)
             bs_launch_plan(ready[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
-                           bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, true);
+                           bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, true, bs_order[slot].ptr);
         CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
         slot_used[slot] = true;
     };
@@ -1189,13 +1203,22 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
     for (int j = 0; j < n_batches; ++j) {
         const int slot = (base_slot + j) & 1;
         const int nb = std::min(max_batch, n_iters - done);
-        if (j + 1 < n_batches) {
-            schedule(slot ^ 1, iter0 + done + nb, std::min(max_batch, n_iters - done - nb));  // beside this batch's iterations
-        } else if (speculate) {  // for the next call: it starts at iter0 + n_iters and is as long as this one
-            schedule(slot ^ 1, iter0 + n_iters, nb_first);
-            spec = Speculated{true, a.seed, iter0 + static_cast<uint64_t>(n_iters), nb_first, a.user_offset, a.indptr, blocksolve,
-                              slot ^ 1, ready[slot ^ 1].sk, ready[slot ^ 1].sv};
-        }
+        // The next batch's schedule is queued (on its own stream) BEHIND this batch's first iterations in host order: queueing it
+        // costs the host tens of microseconds (the segmented sort's launches), and at the start of a call the device is idle -- with
+        // the schedule queued first, the call's first phase 1 started ~100 us after the call did (kernel traces, round 4: every call
+        // of 20 iterations paid 5 us per iteration for it).
+        bool next_scheduled = false;
+        auto schedule_next = [&] {
+            if (next_scheduled) return;
+            next_scheduled = true;
+            if (j + 1 < n_batches) {
+                schedule(slot ^ 1, iter0 + done + nb, std::min(max_batch, n_iters - done - nb));  // beside this batch's iterations
+            } else if (speculate) {  // for the next call: it starts at iter0 + n_iters and is as long as this one
+                schedule(slot ^ 1, iter0 + n_iters, nb_first);
+                spec = Speculated{true, a.seed, iter0 + static_cast<uint64_t>(n_iters), nb_first, a.user_offset, a.indptr, blocksolve,
+                                  slot ^ 1, ready[slot ^ 1].sk, ready[slot ^ 1].sv};
+            }
+        };
         CU2REC_HIP(hipStreamWaitEvent(stream, ev_ready[slot], 0));
         const uint32_t *sk = ready[slot].sk;
         const uint64_t *sv = ready[slot].sv;
@@ -1215,8 +1238,9 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             //    HIP runtime multiplexes streams onto a small pool of queues, and two of these launches in one queue would wait
             //    for each other until the bounded waits give up -- so it is not the default.
             static const bool concurrent = std::getenv("CU2REC_BS_CONCURRENT") != nullptr && std::atoi(std::getenv("CU2REC_BS_CONCURRENT")) != 0;
-            if (concurrent) CU2REC_HIP(hipStreamWaitEvent(solve, ev_ready[slot], 0));
+            CU2REC_HIP(hipStreamWaitEvent(solve, ev_ready[slot], 0));  // (concurrent: phase 2; pipelined: phase 3)
             CU2REC_HIP(hipStreamWaitEvent(upd, ev_ready[slot], 0));
+            bool pipe_used = false;
             const double la = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.q_reg));
             const double lc = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.ib_reg));
             unsigned *status = bs_status_word();
@@ -1240,6 +1264,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 aff_nslots = a.nslots;
             }
             for (int b = 0; b < nb; ++b) {
+                if (b == std::min(2, nb - 1) && b > 0) schedule_next();  // (two iterations are queued: the device has work)
                 a.iter0 = iter0 + done + b;
                 if (++bs_epoch == 0) ++bs_epoch;
                 BsIteration it{};
@@ -1250,6 +1275,10 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.item_mask = item_mask;
                 it.chains = bs_chains[slot].ptr + static_cast<size_t>(b) * std::max(n_hot_bs, 1);
                 it.blocks = bs_blocks[slot].ptr + static_cast<size_t>(b) * max_blocks;
+                it.order = bs_order[slot].ptr + static_cast<size_t>(b) * max_blocks;
+                it.pipe = 0;
+                it.pipe_done = pipe_done.ptr;
+                it.pipe_target = 0;
                 it.walk_begin = walk_begin[slot].ptr + b;
                 it.item_of_rank = item_of_rank.ptr;
                 it.tables = tables.ptr;
@@ -1315,28 +1344,56 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                         if (markers) CU2REC_HIP(hipEventRecord(ev_gram, stream));
                         CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
                     }
+                    // Pipelined (CU2REC_BS_PIPE=1, opt-in): phase 3 runs BESIDE phase 2 as a grid of persistent workgroups on the third
+                    // stream, behind a gate of its own (phase 2's workgroups hold their CUs: a CU filled with waiting phase-3 workgroups
+                    // would have no room for a chain), taking each block as soon as its chain has announced it; what is left of phase 3
+                    // behind the longest chain is its last block, and the join -- with phase 3 AND the side kernel -- is one more
+                    // workgroup in phase 2's launch.  Measured SLOWER than phase 3 behind phase 2 (round 4, ML-20M shape: 88.5 against
+                    // 82.4 us per step): phase 3 moves 37 MB and the side kernel, which it then runs beside, is bound by the same memory
+                    // system (57.6 instead of 44.9 us) -- DESIGN.md section 4.
+                    static const bool pipe_ok = std::getenv("CU2REC_BS_PIPE") && std::atoi(std::getenv("CU2REC_BS_PIPE")) != 0;
+                    const bool pipe = pipe_ok && device_join && it.gram_done && aff_min == 0 && bs_pipe_supported(a.nslots);
+                    const int pipe_grid = std::min(max_blocks, blocksolve_pipe_grid(0));
+                    // The join: a signal kernel behind the side kernel, and one more workgroup in the main stream's last launch of the
+                    // iteration that waits for its word (the number is known before either is queued: the wait is on the device) -- the
+                    // next phase 1 follows that launch without an event.
+                    // (CU2REC_BS_DBG & 16, fault-path test: the signal is never sent -- the waiting workgroup gives up after
+                    // 15 x the bound, the status word is set and the next entry point returns CU2REC_EHIP)
+                    if (device_join) {
+                        it.side_seq = side_seq.ptr;
+                        it.side_target = side_seq_host + 1;
+                    }
+                    if (pipe) {
+                        it.pipe = 1;
+                        it.pipe_target = pipe_done_host + static_cast<unsigned long long>(pipe_grid);
+                    }
                     bs_launch_solve(a, it, stream);
-                    if (it.gram_done) started_total += static_cast<unsigned long long>(n_hot_bs);  // (counted by its workgroups only then)
+                    if (it.gram_done) started_total += static_cast<unsigned long long>(n_hot_bs + (pipe ? 1 : 0));  // (counted by its workgroups only then)
                     // (the gate behind phase 2 in host order: it also waits for phase 2's workgroups to hold their CUs)
                     // (CU2REC_BS_DBG & 32, fault-path test: a gate that can never be satisfied -- it gives up after the bound and the run
                     // goes on, results unchanged)
                     if (it.gram_done)
                         bs_launch_gate(gram_done.ptr, gram_done_target + ((dbg & 32) ? (1ull << 40) : 0ull), solve_started.ptr, started_total, upd);
+                    // (the side kernel's completion event is what the main stream waits for at the END of the batch; with the device-side
+                    // join only the batch's last side kernel carries it -- an event on a kernel's completion signal holds the next packet
+                    // of its queue back, here the signal kernel: 5.4 us per iteration in the kernel traces of round 4)
+                    const bool side_event = !markers && (!device_join || b == nb - 1);
                     launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(b) << item_bits,
                                   std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, kRoleDuo | kRoleWalk,
-                                  chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1), markers ? nullptr : ev_upd);
+                                  chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1), side_event ? ev_upd : nullptr);
                     if (markers) CU2REC_HIP(hipEventRecord(ev_upd, upd));
                     if (device_join) {
-                        // a signal kernel behind the side kernel, and one more workgroup in phase 3 that waits for it (queued BEHIND
-                        // the signal in host order): the next phase 1 follows phase 3 without an event
-                        // (CU2REC_BS_DBG & 16, fault-path test: the signal is never sent -- phase 3's waiting workgroup gives up after
-                        // 15 x the bound, the status word is set and the next entry point returns CU2REC_EHIP)
                         ++side_seq_host;
                         if (!(dbg & 16)) bs_launch_signal(side_seq.ptr, side_seq_host, upd);
-                        it.side_seq = side_seq.ptr;
-                        it.side_target = side_seq_host;
                     }
-                    bs_launch_update(a, it, stream);
+                    if (pipe) {
+                        bs_launch_gate(gram_done.ptr, gram_done_target, solve_started.ptr, started_total, solve);
+                        bs_launch_update_pipe(a, it, pipe_grid, solve);
+                        pipe_done_host += static_cast<unsigned long long>(pipe_grid);
+                        pipe_used = true;
+                    } else {
+                        bs_launch_update(a, it, stream);
+                    }
                     upd_pending = true;
                     continue;
                 }
@@ -1364,9 +1421,10 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 CU2REC_HIP(hipEventRecord(ev_upd, upd));
                 upd_pending = true;
             }
+            schedule_next();  // (a batch of one or two iterations)
             CU2REC_HIP(hipGetLastError());
             // the batch's slot is free once all three streams are through with it
-            if (concurrent) {
+            if (concurrent || pipe_used) {
                 CU2REC_HIP(hipEventRecord(ev_solve, solve));
                 CU2REC_HIP(hipStreamWaitEvent(stream, ev_solve, 0));
             }
@@ -1385,6 +1443,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                                 launch_chains_persistent(a, sk, sv, seg, n_active, item_of_rank.ptr, item_mask, n_hot, 0,
                                                          n_hot <= n_range_ranks ? chain_ranges[slot].ptr : nullptr, n_range_ranks + 1, nb, stream);
         for (int b = 0; b < nb && !persistent; ++b) {
+            if (b == std::min(2, nb - 1) && b > 0) schedule_next();
             a.iter0 = iter0 + done + b;
             const uint32_t *kb = sk + static_cast<size_t>(b) * seg;
             const uint64_t *vb = sv + static_cast<size_t>(b) * seg;
@@ -1392,6 +1451,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             launch_chains(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream, 0, kRoleDuo | kRoleWalk,
                           n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1) : nullptr);
         }
+        schedule_next();
         CU2REC_HIP(hipGetLastError());
         CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));
         done += nb;

@@ -67,6 +67,7 @@ struct OrderedSchedule {
     int n_range_ranks = 0;
     DeviceBuffer<BsChainDesc> bs_chains[2];
     DeviceBuffer<BsBlockDesc> bs_blocks[2];
+    DeviceBuffer<int> bs_order[2];  // the pipelined phase 3's block order, per iteration of the batch
     DeviceBuffer<float> tables, Mbuf, ebuf, qstart;
     DeviceBuffer<float> Tbuf, Wbuf, bstart;  // affine form of the long chains' blocks (allocated on first use)
     DeviceBuffer<unsigned long long> hstate;
@@ -76,7 +77,8 @@ struct OrderedSchedule {
     // waits for phase 1 block by block and phase 3 for phase 2 chain by chain through device words tagged with the iteration's
     // epoch (blocksolve.hpp); one event edge per iteration crosses back: phase 3 of iteration i before phase 1 of i + 1 (ev_upd).
     DeviceBuffer<unsigned> gram_flag;
-    DeviceBuffer<unsigned long long> chain_prog, solve_started, gram_done;
+    DeviceBuffer<unsigned long long> chain_prog, solve_started, gram_done, pipe_done;
+    unsigned long long pipe_done_host = 0;  // phase-3 workgroups launched so far (pipelined topology)
     unsigned long long gram_done_target = 0;  // phase-1 workgroups launched so far (what gram_done will reach)
     DeviceBuffer<unsigned long long> side_seq;  // [1] number of the last iteration whose side kernel is complete (bs_launch_signal)
     unsigned long long side_seq_host = 0;
@@ -104,6 +106,7 @@ int ordered_persistent_launches();
 // chains EXPECTED to be at least this many blocks of 64 links long run phase 2 in the look-ahead form (default 24: the top chains; 0: none;
 // schedules created later); blocks < 0 only queries
 int blocksolve_lookahead_blocks(int blocks);
+int blocksolve_pipe_grid(int set);  // workgroups of the pipelined phase 3 (0: query; default 2 per CU, env CU2REC_BLOCKSOLVE_PIPE_GRID)
 // chains of at least this many blocks of 64 links take the affine form (0: none); blocks < 0 only queries
 int blocksolve_affine_blocks(int blocks);
 // ... after their first `blocks` blocks in the plain form (>= 1; 0 only queries)

@@ -426,3 +426,47 @@ def test_blocksolve_gate_that_never_opens_only_costs_time():
     last = _run_fault_script(32)
     assert last.startswith("OK "), last
     assert float(last.split()[1]) <= 2e-6, last
+
+
+_PIPE_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import cu2rec_amd as cu
+from cu2rec_amd import api, synth
+from cu2rec_amd._lib import check, lib
+from oracle import oracle as orc
+hyper = (0.01, 0.02, 0.02, 0.02, 0.02)
+worst = 0.0
+for users, items, nnz, f, iters, rate, la in ((300, 120, 6000, 10, 70, 2.0, 0), (3000, 40, 30000, 100, 6, 1.0, 2), (9000, 6, 40000, 100, 3, 1.0, 4),
+                                              (9000, 6, 40000, 128, 3, 1.0, 0), (2000, 300, 40000, 200, 5, 0.5, 0), (20000, 300, 90000, 16, 3, 8.0, 2)):
+    api.blocksolve_min_rate(rate)
+    api.blocksolve_lookahead_blocks(la)
+    tr, _ = synth.make_ratings(users, items, nnz, min_degree=3, seed=users + f)
+    d_tr = cu.DeviceCSR(tr)
+    assert d_tr.blocksolve_items() > 0
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    model.sgd(d_tr, hyper, 42, 0, iters, mode="blocksolve")
+    check(lib().cu2rec_check_faults())
+    state = orc.init_model(tr.rows, tr.cols, f)
+    orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias), *state, tr.global_bias, hyper, 42, 0,
+                       iters, dot_order=orc.DOT_TREE16)
+    worst = max(worst, max(float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(model.download(), state)))
+print("OK %%.3e" %% worst)
+"""
+
+
+def test_blocksolve_pipelined_topology_matches_sequential_oracle():
+    """The opt-in pipelined launch topology (CU2REC_BS_PIPE=1: phase 3 as persistent workgroups beside phase 2, fed block by block through
+    the chains' progress words; the join in phase 2's launch): plain and look-ahead chains, short and long, a row width it does not take
+    (f = 200: falls back to phase 3 behind phase 2), more chains than CUs -- each against the sequential oracle.  In a process of its own:
+    the setting is read once."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CU2REC_BS_PIPE="1")
+    res = subprocess.run([sys.executable, "-c", _PIPE_SCRIPT % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    last = res.stdout.strip().splitlines()[-1]
+    assert last.startswith("OK "), last
+    assert float(last.split()[1]) <= 2e-6, last
