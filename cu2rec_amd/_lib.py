@@ -76,6 +76,7 @@ SIGNATURES = {
                                     C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "cu2rec_model_item_stride": (C.c_int, [_P]),
     "cu2rec_hogwild_resident_geometry": (C.c_int, [C.c_int, C.c_int, C.c_int, _ip, _ip, _ip]),
+    "cu2rec_hogwild_resident_streamed_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "cu2rec_sgd_update_ex": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,
                                        C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, _P,
                                        _P]),

@@ -528,6 +528,8 @@ int cu2rec_hogwild_resident_geometry(int n_rows, int n_factors, int n_cus, int *
     return resident_geometry(n_rows, n_factors, n_cus, blocks, users_per_group, lds_rows) ? 1 : 0;
 }
 
+int cu2rec_hogwild_resident_streamed_rows(int n_rows, int n_factors, int n_cus) { return resident_streamed_rows(n_rows, n_factors, n_cus); }
+
 int cu2rec_schedule_create(const int *indptr, const int *indices, int n_rows, int n_cols, int nnz,
                            cu2rec_schedule **out) {
     return guarded([&] {

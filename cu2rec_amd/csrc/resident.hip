@@ -77,6 +77,7 @@ struct ResidentArgs {
     unsigned *status;      // set to 1 by a workgroup that gave up waiting (the host reads and clears it)
     float *sink;           // kSinkFloats floats nobody reads: where the updates of users without ratings are written
     int local;             // 1: only the workgroups that share workgroup 0's XCD run (small sets: one L2, no write-back)
+    int streamed;          // partial residency: users per group BEHIND the resident ones whose rows stay in memory (0: none)
 };
 constexpr int kSinkBias = 512;                 // sink[0 .. 511]: an item row, sink[512]: an item bias
 constexpr int kSinkFloats = kSinkBias + 16;
@@ -138,7 +139,12 @@ __device__ __forceinline__ float predict_wrapped(const Row<J> &p, const Row<J> &
 // group at f <= 128 (16 + 9 = 25: 204,000 users on 256 CUs).
 //
 // J: float4 slots per lane (row width), R: users per group, D: item rows in flight per group, RL: rows kept in LDS.
-template <int J, int R, int D, int RL>
+// PART (partial residency, round 4): a set that does not fit the chip.  Every group owns ra.streamed MORE users behind its R resident
+// ones; their rows stay in memory and pass through the same pipeline -- row in with the item row, update, row out -- in chunks of 16
+// users (one lane-distributed set of scalars per chunk, drawn and gathered while the chunk before is worked on; the pipeline is
+// drained at a chunk's end, so that nothing is in flight across the loop's back edge: the compiler's s_waitcnt counts stay exact
+// inside the straight-line chunk).  Netflix shape, 480,189 users at f = 128: 25 of a group's 59-60 rows resident.
+template <int J, int R, int D, int RL, bool PART = false>
 __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, ResidentArgs ra) {
     constexpr int RREG = R - RL;  // rows in registers
     static_assert(D >= 1 && D <= R && RL >= 0 && RREG >= 1, "shape");
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
         alive = s_barrier.ok != 0;
         wg = s_barrier.index;
         n_wg = s_barrier.n_mine;
-        if (static_cast<long long>(n_wg) * kResGroups * R < a.n_rows) {  // fewer workgroups on this XCD than the host counted on
+        if (static_cast<long long>(n_wg) * kResGroups * (R + (PART ? ra.streamed : 0)) < a.n_rows) {  // fewer workgroups on this XCD than the host counted on
             if (threadIdx.x == 0) __hip_atomic_store(ra.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
@@ -255,17 +261,19 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
     const int64_t sink_row_off = reinterpret_cast<char *>(ra.sink) - reinterpret_cast<char *>(a.Q);
     const int64_t sink_bias_off = reinterpret_cast<char *>(ra.sink + kSinkBias) - reinterpret_cast<char *>(a.item_bias);
 
-    auto issue = [&](int r, int s) {  // r, s: constants after unrolling
-        const int set = r / kGroup, src = r % kGroup;
-        q_item[s] = __shfl(item[set], src, kGroup);  // 0 for a user without ratings
-        q_rating[s] = __shfl(rating[set], src, kGroup);
-        q_active[s] = __shfl(my_n[set], src, kGroup) > 0;
+    // (item_l, rating_l, n_l: one lane-distributed set of 16 users; src: the user's lane in it)
+    auto issue_from = [&](int item_l, float rating_l, int n_l, int src, int s) {
+        q_item[s] = __shfl(item_l, src, kGroup);  // 0 for a user without ratings
+        q_rating[s] = __shfl(rating_l, src, kGroup);
+        q_active[s] = __shfl(n_l, src, kGroup) > 0;
         q[s] = load_wrapped<J>(a.Q + static_cast<size_t>(q_item[s]) * a.ldq, sl);
         q_ib[s] = a.item_bias[q_item[s]];
     };
-    auto consume = [&](Row<J> &pc, int c, int s) {
-        const int set = c / kGroup, src = c % kGroup;
-        const float ub = __shfl(my_ub[set], src, kGroup);
+    auto issue = [&](int r, int s) {  // r, s: constants after unrolling
+        issue_from(item[r / kGroup], rating[r / kGroup], my_n[r / kGroup], r % kGroup, s);
+    };
+    auto consume_with = [&](Row<J> &pc, float &ub_l, int src, int s) {  // ub_l: the set's lane-distributed user biases
+        const float ub = __shfl(ub_l, src, kGroup);
         const float ib = q_ib[s];
         const float err = q_rating[s] - predict_wrapped<J>(pc, q[s], ub, ib, a.global_bias, sl.last_valid);  // sgd.cu:45
         rank1_update<J>(pc, q[s], err, a.h);                                                                // sgd.cu:53-64
@@ -284,7 +292,39 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
                 ib + a.h.lr * (err - a.h.ib_reg * ib);  // sgd.cu:71
         }
         const float ub_new = ub + a.h.lr * (err - a.h.ub_reg * ub);  // sgd.cu:67
-        my_ub[set] = (lane == src && q_active[s]) ? ub_new : my_ub[set];
+        ub_l = (lane == src && q_active[s]) ? ub_new : ub_l;
+    };
+    auto consume = [&](Row<J> &pc, int c, int s) { consume_with(pc, my_ub[c / kGroup], c % kGroup, s); };
+    [[maybe_unused]] const int64_t sink_p_off = reinterpret_cast<char *>(ra.sink) - reinterpret_cast<char *>(a.P);
+    // a chunk of streamed users, lane-distributed: everything branch free (clamped addresses, selects), so that it can sit between
+    // the steps of the chunk before without costing them their counted waits
+    struct Chunk {
+        int x, low, n, item;  // x: the user, or a valid row to read for a lane without one (n == 0: never written)
+        float ub, rating;
+    };
+    auto chunk_bounds = [&](int ch, Chunk &c) {
+        const int sidx = ch * kGroup + lane;
+        const int xs = group + (R + sidx) * n_groups;
+        const bool valid = sidx < ra.streamed && xs < a.n_rows;
+        c.x = valid ? xs : 0;
+        const int lo = a.indptr[c.x], hi = a.indptr[c.x + 1];
+        const float ub = a.user_bias[c.x];
+        c.low = lo;
+        c.n = valid ? hi - lo : 0;
+        c.ub = ub;
+    };
+    auto chunk_draw = [&](uint64_t it, Chunk &c) {
+        const int y_i = sampler_index(a.seed, static_cast<uint64_t>(a.user_offset + c.x), it, c.low, c.low + max(c.n, 1));
+        const int at = c.n > 0 ? y_i : 0;
+        if (a.pairs != nullptr) {  // (uniform)
+            const uint2 ir = a.pairs[at];
+            c.item = c.n > 0 ? static_cast<int>(ir.x) : 0;
+            c.rating = __uint_as_float(ir.y);
+        } else {
+            const int yi = a.indices[at];
+            c.rating = a.data[at];
+            c.item = c.n > 0 ? yi : 0;
+        }
     };
 
     for (int k = 0; alive && k < a.iters; ++k) {
@@ -310,6 +350,39 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
                 // keep a step's shuffles and address arithmetic inside the step: hoisted to the top of the
                 // straight-line code they cost ~10 live registers per user, which the resident rows need
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (PART) {
+                const uint64_t it_now = a.iter0 + static_cast<uint64_t>(k);
+                const int n_chunks = (ra.streamed + kGroup - 1) / kGroup;
+                Chunk cur, nxt;
+                chunk_bounds(0, cur);
+                chunk_draw(it_now, cur);
+                for (int ch = 0; ch < n_chunks; ++ch) {
+                    asm volatile("" ::"v"(cur.item), "v"(cur.rating), "v"(cur.ub), "v"(cur.n), "v"(cur.x));  // (the chunk's scalars are here)
+                    Row<J> ps[D];
+#pragma unroll
+                    for (int u = 0; u < kGroup + D; ++u) {
+                        if (u >= D) {
+                            const int c = u - D;
+                            Row<J> row = ps[c % D];
+                            consume_with(row, cur.ub, c, c % D);
+                            const int64_t p_off =
+                                q_active[c % D] ? static_cast<int64_t>(__shfl(cur.x, c, kGroup)) * a.ldp * 4 : sink_p_off;
+                            store_wrapped<J>(reinterpret_cast<float *>(reinterpret_cast<char *>(a.P) + p_off), sl, row);
+                        }
+                        if (u < kGroup) {
+                            issue_from(cur.item, cur.rating, cur.n, u, u % D);
+                            ps[u % D] = load_wrapped<J>(a.P + static_cast<size_t>(__shfl(cur.x, u, kGroup)) * a.ldp, sl);
+                        }
+                        // the next chunk's scalars and draw ride along (a chunk past the last one: clamped, unused)
+                        if (u == 1) chunk_bounds(ch + 1, nxt);
+                        if (u == kGroup / 2) chunk_draw(it_now, nxt);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // the users' biases go back (a lane without a user, or a user without ratings: its own old value, or nothing)
+                    if (cur.n > 0) a.user_bias[cur.x] = cur.ub;
+                    cur = nxt;
+                }
             }
         }
         if (k + 1 == a.iters) break;
@@ -344,11 +417,13 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
 // spilling, plus (the _LDS variants) what the CU's 160 KB of LDS adds.  Capacity on 256 CUs: f <= 64: 385,000 users,
 // f <= 128: 204,000, f <= 192: 114,000, f <= 256: 81,000.
 struct Variant {
-    int j, r, rl;  // rl of the r rows per group live in LDS
+    int j, r, rl;  // rl of the r resident rows per group live in LDS
+    bool part;     // partial residency: any number of further users per group, their rows streamed (ResidentArgs::streamed)
     const void *kernel;
 };
-#define CU2REC_RES_VARIANT(J, R, D) {J, R, 0, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, 0>)}
-#define CU2REC_RES_VARIANT_LDS(J, R, D, RL) {J, R, RL, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, RL>)}
+#define CU2REC_RES_VARIANT(J, R, D) {J, R, 0, false, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, 0>)}
+#define CU2REC_RES_VARIANT_LDS(J, R, D, RL) {J, R, RL, false, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, RL>)}
+#define CU2REC_RES_VARIANT_PART(J, R, D, RL) {J, R, RL, true, reinterpret_cast<const void *>(&sgd_resident_kernel<J, R, D, RL, true>)}
 const Variant kVariants[] = {
     CU2REC_RES_VARIANT(1, 4, 4),   CU2REC_RES_VARIANT(1, 8, 4),   CU2REC_RES_VARIANT(1, 12, 4),  CU2REC_RES_VARIANT(1, 16, 4),
     CU2REC_RES_VARIANT(1, 20, 4),  CU2REC_RES_VARIANT(1, 24, 4),  CU2REC_RES_VARIANT(1, 28, 4),  CU2REC_RES_VARIANT(1, 32, 4),
@@ -363,17 +438,34 @@ const Variant kVariants[] = {
     CU2REC_RES_VARIANT_LDS(3, 10, 3, 2), CU2REC_RES_VARIANT_LDS(3, 12, 3, 4), CU2REC_RES_VARIANT_LDS(3, 14, 3, 6),
     CU2REC_RES_VARIANT(4, 4, 2),   CU2REC_RES_VARIANT(4, 6, 2),
     CU2REC_RES_VARIANT_LDS(4, 8, 2, 2), CU2REC_RES_VARIANT_LDS(4, 10, 2, 4),
+    // partial residency: one form per row width (a few register rows fewer than the largest resident form: the streamed rows'
+    // pipeline and a chunk's scalars live in them)
+    CU2REC_RES_VARIANT_PART(1, 39, 4, 19), CU2REC_RES_VARIANT_PART(2, 20, CU2REC_RES_D2, 9), CU2REC_RES_VARIANT_PART(3, 11, 3, 6),
+    CU2REC_RES_VARIANT_PART(4, 8, 2, 4),
 };
 #undef CU2REC_RES_VARIANT
 #undef CU2REC_RES_VARIANT_LDS
+#undef CU2REC_RES_VARIANT_PART
 constexpr int kNumVariants = static_cast<int>(sizeof(kVariants) / sizeof(kVariants[0]));
 
-// smallest compiled variant with this J and at least `need` users per group; -1 if none
-int variant_for(int j, int need) {
+// smallest fully resident compiled variant with this J and at least `need` users per group; else (if `partial`) the partially
+// resident form of this J, whose further users stream; -1 if none
+int variant_for(int j, int need, bool partial = false) {
     int best = -1;
     for (int i = 0; i < kNumVariants; ++i)
-        if (kVariants[i].j == j && kVariants[i].r >= need && (best < 0 || kVariants[i].r < kVariants[best].r)) best = i;
+        if (kVariants[i].j == j && !kVariants[i].part && kVariants[i].r >= need && (best < 0 || kVariants[i].r < kVariants[best].r)) best = i;
+    if (best >= 0 || !partial) return best;
+    for (int i = 0; i < kNumVariants; ++i)
+        if (kVariants[i].j == j && kVariants[i].part) best = i;
     return best;
+}
+
+// Partial residency (CU2REC_RESIDENT_PARTIAL=0 switches it off: sets that do not fit stream, as before round 4) pays while a
+// fair share of the rows is resident: at most kMaxStreamedPerResident streamed users per resident one.
+constexpr int kMaxStreamedPerResident = 3;
+bool resident_partial_allowed() {
+    static const bool on = !(std::getenv("CU2REC_RESIDENT_PARTIAL") && std::atoi(std::getenv("CU2REC_RESIDENT_PARTIAL")) == 0);
+    return on;
 }
 
 struct DeviceState {
@@ -489,12 +581,20 @@ void resident_check_fault() {
 namespace {
 
 // variant index (or -1) and, through `need` / `blocks`, rows per group needed and the grid of the chosen variant
-int geometry(int n_rows, int nslots, int n_cus, int &need, int &blocks) {
+// ... `streamed`: users per group whose rows stream (0: fully resident)
+int geometry(int n_rows, int nslots, int n_cus, int &need, int &blocks, int &streamed) {
+    streamed = 0;
     if (n_rows < 1 || nslots < 1 || n_cus < 1) return -1;
     const long long max_groups = static_cast<long long>(n_cus) * kResGroups;
     need = static_cast<int>(std::min<long long>((n_rows + max_groups - 1) / max_groups, 1 << 20));
-    const int v = variant_for(slots_per_lane(nslots), need);
-    if (v < 0) return -1;  // the rows do not fit registers + LDS
+    const int v = variant_for(slots_per_lane(nslots), need, resident_partial_allowed());
+    if (v < 0) return -1;  // the rows do not fit registers + LDS, and no partial form is compiled for this width
+    if (kVariants[v].part) {  // the whole chip, every group its share: the first r users of a group resident, the others streamed
+        streamed = std::max(need - kVariants[v].r, 0);
+        if (streamed > kMaxStreamedPerResident * kVariants[v].r) return -1;  // too few rows would be resident: stream them all
+        blocks = n_cus;
+        return v;
+    }
     const int r = kVariants[v].r;  // >= need: the grid shrinks instead of running empty steps
     const long long groups = (n_rows + static_cast<long long>(r) - 1) / r;
     blocks = static_cast<int>((groups + kResGroups - 1) / kResGroups);
@@ -504,20 +604,27 @@ int geometry(int n_rows, int nslots, int n_cus, int &need, int &blocks) {
 }  // namespace
 
 bool resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group, int *lds_rows) {
-    int need = 0, b = 0;
-    const int v = n_factors >= 1 ? geometry(n_rows, (n_factors + 3) / 4, n_cus, need, b) : -1;
+    int need = 0, b = 0, streamed = 0;
+    const int v = n_factors >= 1 ? geometry(n_rows, (n_factors + 3) / 4, n_cus, need, b, streamed) : -1;
     if (v < 0) return false;
     if (blocks) *blocks = b;
-    if (users_per_group) *users_per_group = kVariants[v].r;
+    if (users_per_group) *users_per_group = kVariants[v].r + streamed;
     if (lds_rows) *lds_rows = kVariants[v].rl;
     return true;
+}
+
+int resident_streamed_rows(int n_rows, int n_factors, int n_cus) {
+    int need = 0, b = 0, streamed = 0;
+    const int v = n_factors >= 1 ? geometry(n_rows, (n_factors + 3) / 4, n_cus, need, b, streamed) : -1;
+    return v < 0 ? -1 : streamed;
 }
 
 namespace {
 
 // The launch geometry a call would get, or false if it would stream.  Caller holds g_mutex.
 bool plan_locked(int n_rows, int nslots, int n_iters, int update_items, DeviceState *&state, int &variant, int &blocks,
-                 int &users_per_group, bool &local) {
+                 int &users_per_group, bool &local, int &streamed) {
+    streamed = 0;
     const int policy = resident_policy(-1);
     local = false;
     if (policy == kResidentOff || n_iters < 1 || n_rows < 1 || !update_items) return false;
@@ -535,12 +642,12 @@ bool plan_locked(int n_rows, int nslots, int n_iters, int update_items, DeviceSt
             return true;
         }
     }
-    variant = geometry(n_rows, nslots, s.cus, need, blocks);
+    variant = geometry(n_rows, nslots, s.cus, need, blocks, streamed);
     if (variant < 0 || !s.usable[variant]) return false;  // the rows do not fit: stream them
     // Auto: the barrier costs a few microseconds where a kernel boundary costs one or two, so residency pays once
     // an iteration moves enough rows per group and the launch is long enough to amortise loading them.
     if (policy == kResidentAuto && (need < 4 || n_iters < 4)) return false;
-    users_per_group = kVariants[variant].r;
+    users_per_group = kVariants[variant].r + streamed;
 #ifdef CU2REC_RES_TEST_OVERSUBSCRIBE  // fault-path check only (tools/build_variant.sh): a grid that cannot be co-resident
     blocks *= CU2REC_RES_TEST_OVERSUBSCRIBE;
 #endif
@@ -562,9 +669,9 @@ int resident_refusals() {
 bool resident_plan(int n_rows, int n_factors, int n_iters, int *blocks_out, int *users_per_group_out) {
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceState *s = nullptr;
-    int variant = -1, blocks = 0, users_per_group = 0;
+    int variant = -1, blocks = 0, users_per_group = 0, streamed = 0;
     bool local = false;
-    const bool yes = plan_locked(n_rows, (n_factors + 3) / 4, n_iters, 1, s, variant, blocks, users_per_group, local);
+    const bool yes = plan_locked(n_rows, (n_factors + 3) / 4, n_iters, 1, s, variant, blocks, users_per_group, local, streamed);
     if (yes && local) blocks = s->cus / kXcds;  // the workgroups that run
     if (blocks_out) *blocks_out = yes ? blocks : 0;
     if (users_per_group_out) *users_per_group_out = yes ? users_per_group : 0;
@@ -574,15 +681,15 @@ bool resident_plan(int n_rows, int n_factors, int n_iters, int *blocks_out, int 
 bool resident_launch(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream) {
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceState *sp = nullptr;
-    int variant = -1, blocks = 0, users_per_group = 0;
+    int variant = -1, blocks = 0, users_per_group = 0, streamed = 0;
     bool local = false;
-    if (!plan_locked(a.n_rows, a.nslots, n_iters, a.update_items, sp, variant, blocks, users_per_group, local)) return false;
+    if (!plan_locked(a.n_rows, a.nslots, n_iters, a.update_items, sp, variant, blocks, users_per_group, local, streamed)) return false;
     DeviceState &s = *sp;
 
     if (s.have_last && s.last_stream != stream) CU2REC_HIP(hipStreamWaitEvent(stream, s.done, 0));  // never two at once
     a.iter0 = iter0;
     a.iters = n_iters;
-    ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink, local ? 1 : 0};
+    ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink, local ? 1 : 0, streamed};
     void *args[] = {&a, &ra};
     CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));  // counters start from zero
     // A cooperative launch: the runtime checks the grid against what can be co-resident and REFUSES a larger one up

@@ -28,6 +28,8 @@ bool resident_plan(int n_rows, int n_factors, int n_iters, int *blocks, int *use
 // The arithmetic behind resident_plan, device independent: geometry for n_rows users on n_cus CUs, or false if the rows
 // do not fit registers + LDS (policy and call length are not considered).
 bool resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group, int *lds_rows);
+// rows per group that stream in that geometry (partial residency): 0 = fully resident, -1 = no compiled form holds the set
+int resident_streamed_rows(int n_rows, int n_factors, int n_cus);
 
 // Launches the runtime refused on the current device because the grid could not be co-resident (those calls streamed).
 int resident_refusals();

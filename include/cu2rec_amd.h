@@ -253,6 +253,12 @@ int cu2rec_hogwild_resident_plan(int n_rows, int n_factors, int n_iters, int *bl
  * *lds_rows live in LDS; all may be NULL), 0 if they do not.  Policy and call length are not considered. */
 int cu2rec_hogwild_resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group,
                                      int *lds_rows);
+/* Partial residency (round 4; n_factors <= 128): a set too large for the chip still runs as ONE launch per call -- the first
+ * users_per_group - s users of every group resident as above, the other s streamed through the same pipeline, row in, update,
+ * row out (the reference's loop is sgd.cu:22-75 either way).  Returns s for the geometry above: 0 = fully resident, > 0 = that
+ * many streamed rows per group, -1 = no compiled form holds the set (one launch per iteration).  CU2REC_RESIDENT_PARTIAL=0
+ * switches the partial forms off. */
+int cu2rec_hogwild_resident_streamed_rows(int n_rows, int n_factors, int n_cus);
 
 /* Workspace of CU2REC_SGD_ORDERED for one device CSR: item popularity ranks, key/value buffers of the
  * per-iteration schedule, sort scratch.  indptr / indices are device pointers (read once at creation). */

@@ -122,6 +122,22 @@ def test_resident_every_row_width(f, users):
     _run_and_compare(m, f, 7, 6, FORCE)
 
 
+@pytest.mark.parametrize("f,users,streamed", [(128, 230000, 9), (100, 300000, 17), (64, 450000, 16), (256, 100000, 5), (160, 140000, 7)])
+def test_partial_residency_bit_exact_across_the_grid_barrier(f, users, streamed):
+    """Round 4: a set that does not fit the chip still runs as ONE launch per call -- every group's first rows resident, `streamed`
+    more per group passing through the same pipeline from and to memory in chunks of 16 (one chunk, a chunk and a bit, exactly one
+    chunk; J = 1..4).  Bit for bit the oracle on a collision-free set, resumed from a non-zero iteration, users without ratings
+    among the streamed ones."""
+    import ctypes as C
+    assert cu.lib().cu2rec_hogwild_resident_streamed_rows(users, f, 256) == streamed
+    m = _collision_free_set(users, 2 * users + 64, 3, 5, 5, seed=f + 1, empty_every=53)
+    with resident_policy(FORCE):
+        blocks, rows = C.c_int(0), C.c_int(0)
+        assert cu.lib().cu2rec_hogwild_resident_plan(users, f, 5, C.byref(blocks), C.byref(rows)) == 1
+        assert rows.value * blocks.value * 32 >= users
+    _run_and_compare(m, f, 5, 5, FORCE, chunks=[3, 2])
+
+
 def test_resident_frozen_items_need_no_barrier():
     """is_train == false: item side untouched, users fit as in predict.cu; equal to the oracle on ANY input
     because nothing is shared between users."""

@@ -214,11 +214,17 @@ def test_resident_geometry_arithmetic():
     assert geometry(147000, 128) == (1, 256, 18, 0)     # the most the registers hold at two float4 per lane
     assert geometry(162541, 100) == (1, 254, 20, 4)     # ML-25M shape: 4 of 20 rows in LDS
     assert geometry(204800, 128) == (1, 256, 25, 9)     # registers + 147 KB of LDS
-    assert geometry(204801, 128)[0] == 0                # one more does not fit: the call streams
-    assert geometry(480189, 128)[0] == 0                # Netflix shape, one GPU
+    streamed = L.cu2rec_hogwild_resident_streamed_rows
+    assert streamed(204800, 128, 256) == 0 and streamed(138493, 100, 256) == 0
+    # one more does not fit: partial residency (round 4) -- the whole chip, 20 resident rows per group (11 in registers, 9 in LDS)
+    # and 6 streamed ones
+    assert geometry(204801, 128) == (1, 256, 26, 9) and streamed(204801, 128, 256) == 6
+    assert geometry(480189, 128) == (1, 256, 59, 9) and streamed(480189, 128, 256) == 39  # Netflix shape, one GPU: 20 of 59 resident
     assert geometry(60024, 128) == (1, 235, 8, 0)       # ... and one of its eight shards
     assert geometry(6040, 50) == (1, 48, 4, 0)          # small sets round up to 4 rows per group on a smaller grid
-    assert geometry(385024, 64)[0] == 1 and geometry(385025, 64)[0] == 0
+    assert geometry(385024, 64)[0] == 1 and streamed(385024, 64, 256) == 0 and streamed(385025, 64, 256) == 9
+    assert geometry(39 * 4 * 8192, 64)[0] == 1 and geometry(39 * 4 * 8192 + 1, 64)[0] == 0  # at most three streamed users per resident one
+    assert streamed(39 * 4 * 8192 + 1, 64, 256) == -1
     assert geometry(20000, 300)[0] == 0                 # five float4 per lane: no resident variant compiled
     assert geometry(1000, 100, cus=0)[0] == 0
     for rows, f in ((138493, 100), (162541, 100), (60024, 128), (6040, 50), (60000, 200), (77777, 256)):
