@@ -1542,12 +1542,7 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
                                                 const BsChainDesc &cd) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nslots = a.nslots, RS = nslots | 1;
-#ifdef CU2REC_LA_HALVE  // timing only (wrong results; tools/build_variant.sh): a look-ahead chain runs HALF its blocks -- what a block
-                        // twice as fast would give the iteration (profiles/r04_lookahead_ceiling.txt)
-    const int begin = cd.begin, len = max(kB, (cd.len / 2) & ~(kB - 1)), nblk = (len + kB - 1) / kB, g0 = cd.blk0, y = cd.item;
-#else
     const int begin = cd.begin, len = cd.len, nblk = (len + kB - 1) / kB, g0 = cd.blk0, y = cd.item;
-#endif
     float4 *pring = smem;                                        // [kLaPRing][kB][RS]
     float4 *rring = pring + kLaPRing * kB * RS;                  // [kLaRRing][kLaRec4]
     float4 *qbuf = rring + kLaRRing * kLaRec4;                   // [2][kLaQ4] the item row in front of block i: buffer i & 1, zero beyond the row
