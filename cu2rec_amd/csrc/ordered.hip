@@ -1103,11 +1103,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
     if (const char *env = std::getenv("CU2REC_ORDERED_HOT")) hot_wanted = std::max(0, std::atoi(env));  // tuning aid
     const int n_hot = std::min(std::min(n_cols, hot_wanted), static_cast<int>(item_mask));
     // Sample + sort (+ plan) of one batch into a slot, on the schedule stream: nothing in it depends on the model.
-    struct Scheduled {
-        const uint32_t *sk;
-        const uint64_t *sv;
-    } ready[2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    const int n_batches = (n_iters + max_batch - 1) / max_batch;
+
     // SEGMENTED (default): the keys carry the rank only, and every iteration of the batch is sorted as a segment of its own
     // (hipcub::DeviceSegmentedRadixSort: one workgroup per long segment; stable, so the order is the one the sort of the whole
     // batch by (iteration, rank) gives).  The whole-batch sort is three chip-filling passes of 130 us each per 64 iterations,
@@ -1119,6 +1115,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
     static const bool tile_keys = !(std::getenv("CU2REC_SCHED_KEYS_TILE") && std::atoi(std::getenv("CU2REC_SCHED_KEYS_TILE")) == 0);  // max_batch <= 64
     const size_t seg = segmented ? static_cast<size_t>(n_rows) : static_cast<size_t>(n_active);  // an iteration's stride in the sorted arrays
     auto schedule = [&](int slot, uint64_t first_iter, int nb) {
+        win[slot].valid = false;  // (until everything below has been queued: a launch that throws leaves no window behind)
         if (segmented) {
             const size_t n = static_cast<size_t>(nb) * n_rows;
             const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 1 << 16));
@@ -1136,12 +1133,12 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                                                                            vals[slot][1].ptr, static_cast<unsigned>(n), static_cast<unsigned>(nb),
                                                                            seg_offsets.ptr, seg_offsets.ptr + 1, 0u,
                                                                            static_cast<unsigned>(item_bits + 1), sched));
-            ready[slot] = Scheduled{keys[slot][1].ptr, vals[slot][1].ptr};
-            hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, ready[slot].sk, n_active, n_range_ranks, item_bits,
+            win[slot] = Window{true, a.seed, first_iter, nb, a.user_offset, a.indptr, blocksolve, keys[slot][1].ptr, vals[slot][1].ptr};
+            hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, win[slot].sk, n_active, n_range_ranks, item_bits,
                                chain_ranges[slot].ptr, seg, 0);
             CU2REC_HIP(hipGetLastError());
             if (blocksolve)
-                bs_launch_plan(ready[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
+                bs_launch_plan(win[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
                                bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, false, bs_order[slot].ptr);
             CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
             slot_used[slot] = true;
@@ -1166,33 +1163,24 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         size_t bytes = temp_bytes;
         CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(temp.ptr, bytes, dk, dv, static_cast<int>(n), 0,
                                                       item_bits + b_bits + 1, sched));
-        ready[slot] = Scheduled{dk.Current(), dv.Current()};
-        hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, ready[slot].sk, n_active, n_range_ranks, item_bits,
+        win[slot] = Window{true, a.seed, first_iter, nb, a.user_offset, a.indptr, blocksolve, dk.Current(), dv.Current()};
+        hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, win[slot].sk, n_active, n_range_ranks, item_bits,
                            chain_ranges[slot].ptr, seg, 1);
         CU2REC_HIP(hipGetLastError());
         if (blocksolve)
-            bs_launch_plan(ready[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
+            bs_launch_plan(win[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
                            bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, true, bs_order[slot].ptr);
         CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
         slot_used[slot] = true;
     };
-    // A call usually continues where the last one stopped, with as many iterations (cu2rec_train's segments, a bench's
-    // steps): the last call scheduled that batch speculatively.  If this is it, its first batch is already sorted.
-    const int nb_first = std::min(max_batch, n_iters);
-    int base_slot = 0;
-    const bool hit = spec.valid && spec.seed == a.seed && spec.iter0 == iter0 && spec.nb == nb_first &&
-                     spec.user_offset == a.user_offset && spec.indptr == a.indptr && spec.blocksolve == blocksolve;
-    if (hit) {
-        base_slot = spec.slot;
-        ready[base_slot] = Scheduled{spec.sk, spec.sv};
-    } else {
-        // the CSR / model pointers the schedule reads must be final: whatever the caller queued on `stream` so far
-        CU2REC_HIP(hipEventRecord(ev_consumed[1], stream));
-        CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[1], 0));
-        slot_used[1] = true;  // (that record also stands for "slot 1 free": nothing of it is queued behind this point)
-        schedule(0, iter0, nb_first);
-    }
-    spec.valid = false;
+    // A call usually continues where the last one stopped (cu2rec_train's segments, a bench's steps, a sharded run's periods): its
+    // iterations are then already scheduled -- in the window the earlier calls have been running out of, or in the one that was
+    // scheduled ahead beside them.  Otherwise (first call, another seed / offset / mode, a jump in the iteration number) a window
+    // for what this call needs is scheduled now, and the call's first iteration waits for it.
+    auto holds = [&](const Window &w, uint64_t it) {
+        return w.valid && w.seed == a.seed && w.user_offset == a.user_offset && w.indptr == a.indptr && w.blocksolve == blocksolve &&
+               it >= w.iter_begin && it < w.iter_begin + static_cast<uint64_t>(w.nb);
+    };
     if (blocksolve) {  // the other two streams of the mode start behind everything the caller has queued so far
         CU2REC_HIP(hipEventRecord(ev_call, stream));
         CU2REC_HIP(hipStreamWaitEvent(solve, ev_call, 0));
@@ -1200,28 +1188,37 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
     }
     bool upd_pending = false;  // phase 3 of an earlier iteration of THIS call has not been waited for by `stream` yet
     int done = 0;
-    for (int j = 0; j < n_batches; ++j) {
-        const int slot = (base_slot + j) & 1;
-        const int nb = std::min(max_batch, n_iters - done);
-        // The next batch's schedule is queued (on its own stream) BEHIND this batch's first iterations in host order: queueing it
-        // costs the host tens of microseconds (the segmented sort's launches), and at the start of a call the device is idle -- with
-        // the schedule queued first, the call's first phase 1 started ~100 us after the call did (kernel traces, round 4: every call
-        // of 20 iterations paid 5 us per iteration for it).
-        bool next_scheduled = false;
+    while (done < n_iters) {
+        const uint64_t it_first = iter0 + static_cast<uint64_t>(done);
+        int slot = holds(win[0], it_first) ? 0 : (holds(win[1], it_first) ? 1 : -1);
+        if (slot < 0) {
+            // the CSR / model pointers the schedule reads must be final: whatever the caller queued on `stream` so far
+            CU2REC_HIP(hipEventRecord(ev_consumed[1], stream));
+            CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[1], 0));
+            slot_used[1] = true;  // (that record also stands for "slot 1 free": nothing of it is queued behind this point)
+            win[1].valid = false;
+            schedule(0, it_first, std::min(max_batch, n_iters - done));
+            slot = 0;
+        }
+        const int off = static_cast<int>(it_first - win[slot].iter_begin);  // the window's iterations [off, off + nb) are this batch
+        const int nb = std::min(n_iters - done, win[slot].nb - off);
+        // The window BEHIND this one is scheduled beside this batch's iterations unless it exists already: as far as this call goes
+        // on, or -- for the calls to come (`speculate`) -- a whole max_batch.  It is queued (on its own stream) BEHIND this batch's
+        // first iterations in host order: queueing it costs the host tens of microseconds (the segmented sort's launches), and at the
+        // start of a call the device is idle -- with the schedule queued first, the call's first phase 1 started ~100 us after the
+        // call did (kernel traces, round 4).
+        const uint64_t next_begin = win[slot].iter_begin + static_cast<uint64_t>(win[slot].nb);
+        const long long call_beyond = static_cast<long long>(iter0 + static_cast<uint64_t>(n_iters)) - static_cast<long long>(next_begin);
+        const int next_nb = speculate ? max_batch : static_cast<int>(std::min<long long>(max_batch, call_beyond));
+        bool next_scheduled = (holds(win[slot ^ 1], next_begin) && win[slot ^ 1].iter_begin == next_begin) || next_nb <= 0;
         auto schedule_next = [&] {
             if (next_scheduled) return;
             next_scheduled = true;
-            if (j + 1 < n_batches) {
-                schedule(slot ^ 1, iter0 + done + nb, std::min(max_batch, n_iters - done - nb));  // beside this batch's iterations
-            } else if (speculate) {  // for the next call: it starts at iter0 + n_iters and is as long as this one
-                schedule(slot ^ 1, iter0 + n_iters, nb_first);
-                spec = Speculated{true, a.seed, iter0 + static_cast<uint64_t>(n_iters), nb_first, a.user_offset, a.indptr, blocksolve,
-                                  slot ^ 1, ready[slot ^ 1].sk, ready[slot ^ 1].sv};
-            }
+            schedule(slot ^ 1, next_begin, next_nb);
         };
         CU2REC_HIP(hipStreamWaitEvent(stream, ev_ready[slot], 0));
-        const uint32_t *sk = ready[slot].sk;
-        const uint64_t *sv = ready[slot].sv;
+        const uint32_t *sk = win[slot].sk + static_cast<size_t>(off) * seg;   // (the batch's first iteration inside the window)
+        const uint64_t *sv = win[slot].sv + static_cast<size_t>(off) * seg;
         a.iters = 1;
         if (blocksolve) {
             // One iteration = four launches: phase 1 (bs_gram_kernel: every block's inverse factor), phase 2 (bs_solve_kernel: one
@@ -1273,13 +1270,13 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.n_active = n_active;
                 it.n_hot = n_hot_bs;
                 it.item_mask = item_mask;
-                it.chains = bs_chains[slot].ptr + static_cast<size_t>(b) * std::max(n_hot_bs, 1);
-                it.blocks = bs_blocks[slot].ptr + static_cast<size_t>(b) * max_blocks;
-                it.order = bs_order[slot].ptr + static_cast<size_t>(b) * max_blocks;
+                it.chains = bs_chains[slot].ptr + static_cast<size_t>(off + b) * std::max(n_hot_bs, 1);
+                it.blocks = bs_blocks[slot].ptr + static_cast<size_t>(off + b) * max_blocks;
+                it.order = bs_order[slot].ptr + static_cast<size_t>(off + b) * max_blocks;
                 it.pipe = 0;
                 it.pipe_done = pipe_done.ptr;
                 it.pipe_target = 0;
-                it.walk_begin = walk_begin[slot].ptr + b;
+                it.walk_begin = walk_begin[slot].ptr + off + b;
                 it.item_of_rank = item_of_rank.ptr;
                 it.tables = tables.ptr;
                 it.log2a = static_cast<float>(la);
@@ -1378,9 +1375,9 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                     // join only the batch's last side kernel carries it -- an event on a kernel's completion signal holds the next packet
                     // of its queue back, here the signal kernel: 5.4 us per iteration in the kernel traces of round 4)
                     const bool side_event = !markers && (!device_join || b == nb - 1);
-                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(b) << item_bits,
+                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(off + b) << item_bits,
                                   std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, kRoleDuo | kRoleWalk,
-                                  chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1), side_event ? ev_upd : nullptr);
+                                  chain_ranges[slot].ptr + static_cast<size_t>(off + b) * (n_range_ranks + 1), side_event ? ev_upd : nullptr);
                     if (markers) CU2REC_HIP(hipEventRecord(ev_upd, upd));
                     if (device_join) {
                         ++side_seq_host;
@@ -1411,9 +1408,9 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 // other users.  On the SAME stream, behind phase 1: beside it their thousands of workgroups take the CUs away from
                 // phase 1's (measured: 71 instead of 19 us), and a cross-stream edge costs 13-14 us each way on this runtime
                 // (phase 1 -> other chains -> next phase 1 on two streams: 106 us per iteration, 27 of them event latency).
-                launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(b) << item_bits,
+                launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(off + b) << item_bits,
                               std::max(n_duo_bs, n_hot_bs), stream, n_hot_bs, kRoleDuo | kRoleWalk,
-                              chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1));
+                              chain_ranges[slot].ptr + static_cast<size_t>(off + b) * (n_range_ranks + 1));
                 // phase 3 on a stream of its own, behind phase 1 (hence behind the previous iteration's other chains, whose rows
                 // it may rewrite, and behind the start of every phase-2 workgroup): its workgroups wait for the chains' progress
                 CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
@@ -1441,21 +1438,24 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         static const bool persistent_ok = std::getenv("CU2REC_ORDERED_PERSISTENT") && std::atoi(std::getenv("CU2REC_ORDERED_PERSISTENT")) != 0;
         const bool persistent = persistent_ok && segmented && nb >= 2 &&
                                 launch_chains_persistent(a, sk, sv, seg, n_active, item_of_rank.ptr, item_mask, n_hot, 0,
-                                                         n_hot <= n_range_ranks ? chain_ranges[slot].ptr : nullptr, n_range_ranks + 1, nb, stream);
+                                                         n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(off) * (n_range_ranks + 1) : nullptr,
+                                                         n_range_ranks + 1, nb, stream);
         for (int b = 0; b < nb && !persistent; ++b) {
             if (b == std::min(2, nb - 1) && b > 0) schedule_next();
             a.iter0 = iter0 + done + b;
             const uint32_t *kb = sk + static_cast<size_t>(b) * seg;
             const uint64_t *vb = sv + static_cast<size_t>(b) * seg;
-            const uint32_t key_base = segmented ? 0u : static_cast<uint32_t>(b) << item_bits;
+            const uint32_t key_base = segmented ? 0u : static_cast<uint32_t>(off + b) << item_bits;
             launch_chains(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream, 0, kRoleDuo | kRoleWalk,
-                          n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(b) * (n_range_ranks + 1) : nullptr);
+                          n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(off + b) * (n_range_ranks + 1) : nullptr);
         }
         schedule_next();
         CU2REC_HIP(hipGetLastError());
         CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));
         done += nb;
     }
+    // (raw pointers: the arrays behind them are the caller's and may change between calls -- no window outlives the call)
+    if (!speculate) win[0].valid = win[1].valid = false;
     if (blocksolve) bs_report_status(stream);  // (every batch ended with `stream` behind the other two streams)
     CU2REC_HIP(hipEventRecord(ev_last, stream));
     last_stream = stream;

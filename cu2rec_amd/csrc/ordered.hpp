@@ -36,16 +36,18 @@ struct OrderedSchedule {
     // Schedule the next call's first batch ahead (it reads the CSR arrays after run() has returned): only where the
     // schedule lives and dies with the CSR it reads, i.e. the owned-object layer (cu2rec_csr); off for raw pointers.
     bool speculate = false;
-    struct Speculated {  // the batch scheduled ahead for the NEXT call (see run())
+    // A scheduled WINDOW of iterations per slot: [iter_begin, iter_begin + nb) of one (seed, user offset, CSR, mode).  A call runs the
+    // iterations it asks for out of whichever window holds them, at whatever offset -- so calls shorter than a window (a bench's
+    // 20 steps, a driver's periods) share one schedule of max_batch iterations instead of paying for a schedule each.
+    struct Window {
         bool valid = false;
-        uint64_t seed = 0, iter0 = 0;
+        uint64_t seed = 0, iter_begin = 0;
         int nb = 0, user_offset = 0;
         const int *indptr = nullptr;
         bool blocksolve = false;
-        int slot = 0;
         const uint32_t *sk = nullptr;
         const uint64_t *sv = nullptr;
-    } spec;
+    } win[2];
     DeviceBuffer<unsigned char> temp;
     DeviceBuffer<int> seg_offsets;  // [max_batch + 1] b * n_rows: the iterations of a batch as segments of the sort
     size_t temp_bytes = 0;
