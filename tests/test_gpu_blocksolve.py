@@ -138,6 +138,25 @@ def test_blocksolve_resume_empty_users_frozen_items_and_lr_change(min_rate):
     assert max(_max_diffs(model, state)) <= 5e-6
 
 
+def test_blocksolve_calls_of_any_length_share_schedule_windows(min_rate):
+    """One DeviceCSR, calls of 7 / 20 / 50 / 3 / 70 iterations that continue each other across the 64-iteration schedule windows
+    (ordered.hip, Window: a call runs out of whichever window holds its iterations, at whatever offset; the plan of the blocks is the
+    window's too), then a jump back into iterations already run, a jump ahead and another seed: after every call the oracle's state
+    within the mode's rounding."""
+    min_rate(2.0)
+    tr, _ = synth.make_ratings(300, 120, 6000, min_degree=3, seed=310)
+    f = 10
+    d = cu.DeviceCSR(tr)
+    assert d.blocksolve_items() > 0
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    state = orc.init_model(tr.rows, tr.cols, f)
+    for k, (seed, it0, n) in enumerate([(42, 0, 7), (42, 7, 20), (42, 27, 50), (42, 77, 3), (42, 80, 70), (42, 5, 10), (42, 300, 9),
+                                        (7, 309, 30), (7, 339, 100)]):
+        model.sgd(d, HYPER, seed, it0, n, mode="blocksolve")
+        orc.sgd_iterations(_as_orc(tr), *state, tr.global_bias, HYPER, seed, it0, n, dot_order=orc.DOT_TREE16)
+        assert max(_max_diffs(model, state)) <= 5e-6, (k, _max_diffs(model, state))
+
+
 def test_blocksolve_raw_pointers_user_offset(min_rate):
     """cu2rec_sgd_update_blocksolve on a user shard: draws are keyed by the global user id."""
     from cu2rec_amd.engine import DeviceRatings, Engine

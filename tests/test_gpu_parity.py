@@ -395,6 +395,28 @@ print("ok")
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
 
 
+def test_sgd_ordered_calls_of_any_length_share_schedule_windows():
+    """Round 4: the schedule lives in windows of max_batch (64) iterations that outlive the call -- a call runs its iterations out
+    of whichever window holds them, at whatever offset.  Calls that continue each other across window borders, a jump back into a
+    window already run, a jump ahead, another seed, a second model on the same ratings, block-solve calls interleaved (their windows
+    carry a plan and are not the ordered mode's): each call is the oracle's bit for bit in the ordered mode."""
+    tr, _ = _small_set()
+    f = 10
+    d = cu.DeviceCSR(tr)
+    calls = [(42, 0, 7), (42, 7, 20), (42, 27, 50), (42, 77, 3), (42, 80, 70), (42, 5, 10), (42, 15, 4), (42, 400, 9), (7, 409, 30),
+             (7, 439, 140)]
+    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    other = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    for k, (seed, it0, n) in enumerate(calls):
+        model.sgd(d, HYPER, seed, it0, n, mode="ordered")
+        if k % 3 == 1:
+            other.sgd(d, HYPER, seed, it0 + n, 5, mode="blocksolve")  # (another mode's window takes a slot in between)
+        orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, seed, it0, n, dot_order=orc.DOT_TREE16)
+        for name, g, w in zip("P Q ub ib".split(), model.download(), (P, Q, ub, ib)):
+            np.testing.assert_array_equal(g, w, err_msg="%s after call %d" % (name, k))
+
+
 def test_sgd_ordered_resume_empty_users_and_frozen_items():
     m = _toy("toy_missing_user.csv")  # user 2 has no ratings: sentinel keys in the schedule
     f = 10
