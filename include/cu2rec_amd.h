@@ -152,7 +152,10 @@ typedef enum cu2rec_sgd_mode {
      * so each iteration is scheduled ahead of time as independent per-item chains whose updates run in
      * ascending user order with the item row held in registers (cu2rec_amd/csrc/ordered.hip).
      * Bit-identical to CU2REC_SGD_SERIAL and to the CPU oracle.  Needs a cu2rec_schedule workspace
-     * (the object layer creates one per cu2rec_csr on first use). */
+     * (the object layer creates one per cu2rec_csr on first use; there the schedule lives in windows of up to 64 iterations
+     * that outlive the call -- a call of any length, continuing the last one or not, runs out of the window that holds its
+     * iterations, and the window behind it is scheduled beside them; with raw pointers no window outlives the call: the
+     * arrays are the caller's). */
     CU2REC_SGD_ORDERED = 2,
     /* The reference GPU kernel's OWN semantics (sgd.cu:22-75 with the loop of training.cu:107-171), for callers that
      * want those trajectories rather than mf_sequential.cu's: every user reads the item side as it was at the start
