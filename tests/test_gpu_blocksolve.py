@@ -306,12 +306,11 @@ def test_blocksolve_full_shape_ml1m_f50_is_the_oracle_bit_for_bit():
 
 
 @pytest.mark.parametrize("policy,name", [(2, "resident"), (0, "streaming")])
-def test_hogwild_gap_to_sequential_is_pinned_at_full_shape(policy, name):
-    """The racy modes do NOT meet the 1e-4 tolerance (popular items lose most of their updates to the race, sgd.cu:18-21);
-    what they do cost is pinned here at BASELINE.json configs[2]'s shape so that it cannot drift unnoticed: against the
-    exact ordered mode on the same data and sample stream, |test RMSE gap| <= 8e-4 after 500 iterations and <= 4e-3
-    after 1,000 (measured in round 2: resident 4e-4 / 2.8e-3, streaming 2e-4 / 2.4e-3), and not below 1e-4 either -- if
-    that ever holds, bench.py's headline mode should change."""
+def test_hogwild_mid_trajectory_gap_to_sequential_stays_bounded_at_full_shape(policy, name):
+    """A regression bound on the racy modes while the model is still moving (popular items lose most of their updates to the
+    race, sgd.cu:18-21), at BASELINE.json configs[2]'s shape against the exact ordered mode on the same data and sample stream:
+    |test RMSE gap| <= 8e-4 after 500 iterations and <= 4e-3 after 1,000 (measured: resident 4e-4 / 2.8e-3, streaming 2e-4 /
+    2.4e-3).  Whether Hogwild meets the north star's bar is decided at CONVERGENCE, by the Tier-2 test below."""
     import bench
     from cu2rec_amd._lib import lib
     tr, te = bench.load_dataset("ml-20m", 20240917, 0, lambda: None)
@@ -329,7 +328,38 @@ def test_hogwild_gap_to_sequential_is_pinned_at_full_shape(policy, name):
     finally:
         lib().cu2rec_hogwild_resident(prev)
     assert gaps[0] <= 8e-4 and gaps[1] <= 4e-3, (name, gaps)
-    assert gaps[1] > 1e-4, (name, gaps)
+
+
+def test_tier2_converged_runs_under_the_reference_schedule_pick_the_headline_mode():
+    """SURVEY.md section 8c Tier 2 as written -- *converged* test RMSE against the sequential result within 1e-4 -- at BASELINE.json
+    configs[2]'s shape (ML-20M shape, f=100): every mode runs the product's train() under the reference's schedule (loss check every
+    500 iterations, patience 2, decay 0.2: training.cu:118,146-155) for 8,000 iterations, by which the learning rate has decayed five
+    to six times (lr < 1e-5: the model has stopped moving).  The outcome, pinned EITHER way (profiles/r05_tier2_converged_*.json holds
+    three sampler seeds per mode and the ML-1M shape):
+      * block-solve (bench.py's `value`): converged gap <= 1e-4 (measured 1.0e-5 ... 1.3e-5);
+      * Hogwild, resident and streaming launches (sgd.cu:18-21's racy semantics): converged gap ABOVE 1e-4 (measured 2.5e-3 ... 8.3e-3
+        and 3.2e-3 ... 3.3e-3): the race delays the minimum of the test RMSE by a check, so the rate decays 500 iterations later and
+        the run freezes somewhere else.  If this assertion ever fails, Hogwild meets the north star's bar and bench.py's headline
+        should become the resident Hogwild form."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import tier2_converged as t2
+    tr, te = bench.load_dataset("ml-20m", 20240917, 0, lambda: None)
+    d_tr, d_te = cu.DeviceCSR(tr), cu.DeviceCSR(te)
+    f, iters, seed = 100, 8000, 42
+    seq, _ = t2.run_mode(cu, d_tr, d_te, f, seed, iters, "ordered")
+    assert seq["converged"] and seq["n_decays"] >= 3 and seq["final_learning_rate"] < 1e-5, seq
+    assert seq["min_test_rmse"] < seq["final_test_rmse"] < 0.83, seq  # the schedule froze the run a little past its minimum
+    gaps = {}
+    for label in ("blocksolve", "hogwild-resident", "hogwild-streaming"):
+        rec, _ = t2.run_mode(cu, d_tr, d_te, f, seed, iters, label)
+        assert rec["converged"], rec
+        gaps[label] = abs(rec["final_test_rmse"] - seq["final_test_rmse"])
+    assert gaps["blocksolve"] <= 1e-4, gaps
+    assert 1e-4 < gaps["hogwild-resident"] <= 2e-2 and 1e-4 < gaps["hogwild-streaming"] <= 2e-2, gaps
 
 
 def test_bin_mf_blocksolve_mode_against_the_oracle_run(tmp_path):
