@@ -85,7 +85,6 @@ SIGNATURES = {
                                              C.c_int, C.c_int, _ip, _P]),
     "cu2rec_sample_pairs_bytes": (C.c_size_t, [C.c_int]),
     "cu2rec_sample_pairs_build": (C.c_int, [_P, _P, C.c_int, _P, _P]),
-    "cu2rec_hogwild_iters_per_launch": (C.c_int, [C.c_int]),
     "cu2rec_hogwild_resident": (C.c_int, [C.c_int]),
     "cu2rec_check_faults": (C.c_int, []),
     "cu2rec_hogwild_resident_refusals": (C.c_int, []),
@@ -97,10 +96,7 @@ SIGNATURES = {
     "cu2rec_sgd_update_blocksolve": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_float,
                                                C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "cu2rec_blocksolve_min_rate": (C.c_float, [C.c_float]),
-    "cu2rec_blocksolve_affine_blocks": (C.c_int, [C.c_int]),
     "cu2rec_blocksolve_lookahead_blocks": (C.c_int, [C.c_int]),
-    "cu2rec_ordered_persistent_launches": (C.c_int, []),
-    "cu2rec_blocksolve_affine_head": (C.c_int, [C.c_int]),
     "cu2rec_csr_blocksolve_items": (C.c_int, [_P]),
     "cu2rec_debug_blocksolve_stamps": (C.c_int, [_P, C.c_int]),
     "cu2rec_loss_workspace_bytes": (C.c_size_t, []),

@@ -395,20 +395,10 @@ def blocksolve_min_rate(rate=0.0):
     return lib().cu2rec_blocksolve_min_rate(float(rate))
 
 
-def blocksolve_affine_blocks(blocks=-1):
-    """cu2rec_blocksolve_affine_blocks: chains of at least this many 64-update blocks take the affine form (0: off)."""
-    return lib().cu2rec_blocksolve_affine_blocks(int(blocks))
-
-
 def blocksolve_lookahead_blocks(blocks=-1):
     """cu2rec_blocksolve_lookahead_blocks: items expected to collect at least this many 64-update blocks per iteration run phase 2
     in the look-ahead form (default 24: the top chains; 0: off; read when a DeviceCSR's schedule is created)."""
     return lib().cu2rec_blocksolve_lookahead_blocks(int(blocks))
-
-
-def blocksolve_affine_head(blocks=0):
-    """cu2rec_blocksolve_affine_head: blocks such a chain runs in the plain form first (>= 1; 0 only queries)."""
-    return lib().cu2rec_blocksolve_affine_head(int(blocks))
 
 
 def loss_raw(indptr, indices, data, n_rows, nnz, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,

@@ -17,12 +17,10 @@
 //   phase 2  bs_solve_kernel   one workgroup per hot chain walks its blocks, lane = link, four solver wavefronts splitting
 //                              each step (a mat-vec with the block's rows, a mat-vec with M, a transposed mat-vec) -- the only
 //                              sequential part; four more wavefronts stream the blocks' rows and factors global -> registers
-//                              -> LDS, four blocks ahead.  Opt-in for long chains (cu2rec_blocksolve_affine_blocks): the
-//                              chain's later blocks as ONE affine map each, built by extra workgroups of the same launch
-//                              while the chain's first blocks run, and applied by a second workgroup (see "which chains take
-//                              the affine form")
-//   phase 3  bs_update_kernel  every block in parallel: the item row as each link saw it = a 64x64 (lower triangular) by
-//                              64xf product (matrix cores again), then the user rows and user biases
+//                              -> LDS, four blocks ahead; the leading (longest) chains in the look-ahead form, whose dependent
+//                              path per block is two 64 x 64 mat-vecs on one wavefront (chain_lookahead)
+//   phase 3  bs_update_kernel  every block in parallel: one wavefront per 64 columns walks down the block's links with the
+//                              reference's own recurrence, the item row as each link saw it in a register; user rows and biases
 //   beside   the other chains  in the ordered mode's own kernel (ordered.hip: two-wave form for chains of a dozen links
 //                              and more, windowed walk for the rest) on a second stream: other items, other users
 // Results equal the sequential ones up to float rounding (not bit for bit: the sums are associated differently).
@@ -63,39 +61,11 @@ __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __buil
 __device__ __forceinline__ f32x2 dup2(float v) { return f32x2{v, v}; }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// A 16-byte store that goes through the XCD's L2 to the memory side at once (sc1) instead of staying dirty in it: data another
-// workgroup of the SAME launch is waiting for.  The instruction is invisible to the compiler's s_waitcnt bookkeeping: every
-// publisher waits with an explicit s_waitcnt vmcnt before it announces anything.  (s_nop: the data registers of a wide store
-// must not be overwritten by the very next vector instruction; the compiler's hazard pass cannot look into the asm block.)
-__device__ __forceinline__ void store_through(float *p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v));  // (no memory clobber: it would fence the LDS traffic around it)
-}
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) {  // global_load sc1: never served from this CU's L1
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// The same accesses as inline assembly, for the chain's loop (bs_solve_kernel): a vector-memory instruction the COMPILER knows of
-// inside that loop makes its s_waitcnt pass put an s_waitcnt vmcnt(0) into the loop body (a loop-carried "maybe pending"), and
-// that wait then also waits for the write-through stores just issued -- 0.65 us per block on the chain's critical path
-// (measured: 2.2 instead of 1.57 us per block).  These forms wait for themselves and leave nothing pending.
-__device__ __forceinline__ unsigned ld_agent_now(const unsigned *p) {
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void st_agent_u64(unsigned long long *p, unsigned long long v) {
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st_agent_u32(unsigned *p, unsigned v) {
-    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void acquire_agent_now() {  // L1 invalidate, complete on return
-    asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-}
-__device__ __forceinline__ void store_through(float *p, float v) {
-    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v));
 }
 // every device-side wait in here is bounded: BsIteration::wait_ticks (bs_wait_ticks(): CU2REC_BS_WAIT_S seconds, default 2) of the 100 MHz wall clock
 
@@ -205,22 +175,17 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
 }
 
 // ---- plan: one workgroup per iteration of the batch --------------------------------------------------------------
-constexpr int kPlanBins = 1024;  // block numbers told apart in phase 3's order (chains of more blocks: the rest in one bin)
 __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict__ keys, int n_active, int n_hot,
                                                       int item_bits, int max_blocks, const int *__restrict__ item_of_rank,
                                                       int *__restrict__ chain_begin, BsChainDesc *__restrict__ chains,
-                                                      BsBlockDesc *__restrict__ blocks, int *__restrict__ walk_begin, size_t stride,
-                                                      int batch_keys, int *__restrict__ order) {
+                                                      BsBlockDesc *__restrict__ blocks, int *__restrict__ walk_begin, size_t stride) {
     __shared__ int s_part[256];
-    __shared__ int s_bin[kPlanBins];  // blocks per block number (the pipelined phase 3's order: see below)
-    for (int i = threadIdx.x; i < kPlanBins; i += 256) s_bin[i] = 0;
     const int b = blockIdx.x, tid = threadIdx.x;
     const uint32_t *kb = keys + static_cast<size_t>(b) * stride;  // iteration b's share of the sorted keys
-    const uint32_t key_base = batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u;  // (keys with / without the iteration above the rank)
     int *cb = chain_begin + static_cast<size_t>(b) * (n_hot + 1);
     BsChainDesc *cd = chains + static_cast<size_t>(b) * max(n_hot, 1);
     BsBlockDesc *bd = blocks + static_cast<size_t>(b) * max_blocks;
-    for (int r = tid; r <= n_hot; r += 256) cb[r] = lower_bound_key(kb, n_active, key_base + static_cast<uint32_t>(r));
+    for (int r = tid; r <= n_hot; r += 256) cb[r] = lower_bound_key(kb, n_active, static_cast<uint32_t>(r));
     __syncthreads();
     if (tid == 0) walk_begin[b] = cb[n_hot];
     // blocks per chain -> exclusive prefix; thread t owns the chains [t * per, (t + 1) * per)
@@ -246,48 +211,10 @@ __global__ __launch_bounds__(256) void bs_plan_kernel(const uint32_t *__restrict
         const int begin = cb[r], len = cb[r + 1] - begin;
         cd[r] = BsChainDesc{begin, len, off, item_of_rank[r]};
         const int nb = (len + kB - 1) / kB;
-        for (int m = 0; m < nb; ++m) {
-            bd[off + m] = BsBlockDesc{begin + kB * m, min(kB, len - kB * m), r, m};
-            atomicAdd(&s_bin[min(m, kPlanBins - 1)], 1);
-        }
+        for (int m = 0; m < nb; ++m) bd[off + m] = BsBlockDesc{begin + kB * m, min(kB, len - kB * m), r, m};
         off += nb;
     }
     for (int g = s_total + tid; g < max_blocks; g += 256) bd[g] = BsBlockDesc{0, 0, 0, 0};
-    // The order in which the pipelined phase 3 (bs_update_pipe_kernel) takes the blocks: by block number first -- the order in which
-    // the chains, all started together, get through with them.  (Which of two blocks of the same number comes first is left to the
-    // atomics: phase 3's result does not depend on its order.)
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < kPlanBins; ++i) {
-            const int v = s_bin[i];
-            s_bin[i] = run;
-            run += v;
-        }
-    }
-    __syncthreads();
-    int *ord = order + static_cast<size_t>(b) * max_blocks;
-    off = s_part[tid];
-    for (int r = r0; r < r1; ++r) {
-        const int nb = (cb[r + 1] - cb[r] + kB - 1) / kB;
-        for (int m = 0; m < nb; ++m) ord[atomicAdd(&s_bin[min(m, kPlanBins - 1)], 1)] = off + m;
-        off += nb;
-    }
-    for (int g = s_total + tid; g < max_blocks; g += 256) ord[g] = g;
-}
-
-// ---- which chains take the affine form (long chains, sequential topology) ---------------------------------------------
-// A chain of rank below aff_tails, of at least aff_min_blocks blocks which all lie below aff_cap, is advanced by TWO workgroups
-// of phase 2's launch: its own runs the first aff_head blocks in the plain form and hands the item's state over through memory;
-// meanwhile one more workgroup per block builds the affine maps T' of the other blocks (affine_build_block), and the chain's
-// second workgroup, which has fetched the first of them by then, runs through those at one mat-vec per block.
-__device__ __forceinline__ bool chain_is_affine(const BsIteration &it, int chain) {
-    const BsChainDesc cd = it.chains[chain];
-    const int nblk = (cd.len + kB - 1) / kB;
-    return it.aff_min_blocks > 0 && chain < it.aff_tails && nblk >= it.aff_min_blocks && cd.blk0 + nblk <= it.aff_cap;
-}
-__device__ __forceinline__ bool block_is_affine(const BsIteration &it, const BsBlockDesc &bd) {
-    return it.aff_min_blocks > 0 && bd.m >= it.aff_head && chain_is_affine(it, bd.chain);
 }
 
 // ---- which chains take the look-ahead form (phase 2, chain_lookahead) -------------------------------------------------------
@@ -421,22 +348,7 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
         return;
     }
     const BsBlockDesc bd = it.blocks[g];
-    if (bd.n_valid == 0) {
-        // The last workgroup of the grid (always an unused block: the grid is an upper bound) keeps this launch alive until
-        // every chain's workgroup of phase 2 has started: phase 3, queued behind this launch, then finds them on their CUs.
-        if (it.concurrent && g == it.max_blocks - 1 && threadIdx.x == 0 && !(it.dbg & 2)) {
-            const unsigned long long t0 = wall_clock64();
-            unsigned polls = 0;
-            while (ld_agent(it.solve_started) < it.started_target) {
-                __builtin_amdgcn_s_sleep(16);
-                if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
-                    __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        return;
-    }
+    if (bd.n_valid == 0) return;  // (the grid is an upper bound of the iteration's blocks)
     const int nslots = a.nslots, RS = nslots | 1;
     // The five 32 x 32 tiles TAKE THE PLACE of the user rows once the Gram products have read them (barrier below): 34.6 instead of
     // 57.6 KB of LDS at f = 128 -- three workgroups a CU instead of two on the Netflix shape, whose 7,500 blocks come in rounds
@@ -601,29 +513,15 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
     stamp.mark(it, 3);
     }  // wave 0
     __syncthreads();
-    // The block's record leaves the workgroup: [M11 | M21 | M22 | base], 16 bytes per lane.  In the concurrent topology
-    // WRITE-THROUGH (sc1) -- the chain's workgroup runs on another CU, usually another XCD, and is already waiting for it in this
-    // same iteration; a plain store would sit dirty in this XCD's L2 until somebody wrote the whole L2 back
-    // (MI355X_MICROARCH.md, "publish-large").
+    // The block's record leaves the workgroup: [M11 | M21 | M22 | base], 16 bytes per lane (phase 2 is queued behind this launch:
+    // the kernel boundary publishes it).
     float *rec = it.Mbuf + static_cast<size_t>(g) * kBsRecFloats;
     {
         const int t = threadIdx.x, row = t >> 3, c4 = t & 7;
         const float *src[3] = {Ms, Ns, Ms + kH * kMS};
-        const bool through = it.concurrent && !(it.dbg & 1);  // queued behind each other, the launch boundary publishes the record
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(src[q] + row * kMS + 4 * c4);
-            if (through) store_through(rec + q * kH * kH + 4 * t, v); else *reinterpret_cast<f32x4 *>(rec + q * kH * kH + 4 * t) = v;
-        }
-        if (t < kB / 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(basev + 4 * t);
-            if (through) store_through(rec + kBsFactorFloats + 4 * t, v); else *reinterpret_cast<f32x4 *>(rec + kBsFactorFloats + 4 * t) = v;
-        }
-    }
-    if (it.concurrent) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's part of the record has left the CU ...
-        __syncthreads();                                   // ... and so has everybody else's: the block may be announced
-        if (threadIdx.x == 0) __hip_atomic_store(it.gram_flag + g, it.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<f32x4 *>(rec + q * kH * kH + 4 * t) = *reinterpret_cast<const f32x4 *>(src[q] + row * kMS + 4 * c4);
+        if (t < kB / 4) *reinterpret_cast<f32x4 *>(rec + kBsFactorFloats + 4 * t) = *reinterpret_cast<const f32x4 *>(basev + 4 * t);
     }
     stamp.done(it, 1, 4 * g + wave);
 }
@@ -671,419 +569,6 @@ __device__ __forceinline__ void solvers_meet(unsigned *meet, unsigned target, in
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// Phase 1 runs in ANOTHER launch at the same time (ordered.hip, "one iteration"): its workgroups announce every block's record
-// with a flag that carries the iteration's epoch.  Solver wavefront 0 keeps `ready` = how many leading blocks of its chain have
-// been announced and waits -- bounded: a chain whose records never arrive gives up, sets the status word and goes on with
-// undefined results, which the host reports -- until `need` are; the acquire that follows (L1 invalidate) makes the loaders' plain loads of
-// those records safe.  Once every block of the chain has been seen this costs one compare.
-__device__ __forceinline__ int await_blocks(const BsIteration &it, int g0, int nblk, int ready, int need, int lane) {
-    need = min(need, nblk);
-    if (ready >= need) return ready;
-    if (it.dbg & 4) return nblk;
-    const unsigned long long t0 = wall_clock64();
-    unsigned polls = 0;
-    for (;;) {
-        const int idx = ready + lane;
-        const unsigned v = ld_agent_now(it.gram_flag + g0 + min(idx, nblk - 1));
-        const unsigned long long mask = __ballot(idx < nblk && v == it.epoch);
-        ready += mask == ~0ull ? 64 : __ffsll(static_cast<unsigned long long>(~mask)) - 1;  // leading announced blocks
-        if (ready >= need) break;
-        __builtin_amdgcn_s_sleep(8);
-        if ((++polls & 31u) == 0 && (ld_agent_now(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
-            if (lane == 0) st_agent_u32(it.status, 1u);
-            ready = nblk;
-            break;
-        }
-    }
-    acquire_agent_now();
-    return ready;
-}
-
-// waits until all but this wavefront's `newest` youngest vector-memory operations have completed (newest <= 6)
-__device__ __forceinline__ void wait_all_but(int newest) {
-    switch (newest) {  // wavefront uniform
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    }
-}
-
-// ---- phase 2, beside the chains: the affine maps of the long chains' later blocks ----------------------------------------
-// One workgroup (eight wavefronts) per block.  From phase 1's record (M = (I + lr L)^-1 in three tiles, the base errors) and
-// the block's 64 user rows:
-//     state s = (item row, item bias), user rows extended by a one, Lambda = diag(a, ..., a, c):
-//     e = M (r' - G s0),  G_k = Lambda^k (p_k, 1);   s_end = Lambda^n s0 + lr H^T e,  H_j = Lambda^(n-1-j) (p_j, 1)
-//     =>  s_end = Lambda^n s0 - lr T' (s0, -1),  T' = H^T W,  W = M [G | r'],  e = -W (s0, -1)
-// (tests/test_blocksolve_algebra.py, affine_chain).  W (64 x 128, MFMA, wavefront w < 4: columns 32 w ..) goes to LDS and to
-// memory for phase 3; T' (128 x 128, wavefront v: rows 32 (v >> 1) .., columns 64 (v & 1) ..) goes to memory WRITE-THROUGH:
-// the chain's workgroup -- another CU of this launch -- is waiting for it (flag per block, epoch tagged).  Every LDS read is
-// unconditional and every choice a multiplication by 0 / 1 or a select on registers: an LDS read inside a conditional becomes
-// a branch with a full wait behind it (the first form of this code, a tail of phase 1, took 18 us per block that way).
-__host__ __device__ inline size_t affine_build_lds_bytes(int nslots) {
-    return (static_cast<size_t>(kB) * (nslots | 1) * 4 + 3 * kH * kMS + kB * bs_affine_ws(nslots) + 3 * kB) * 4;
-}
-
-__device__ __forceinline__ void affine_build_block(const SgdArgs &a, const BsIteration &it, int g, float4 *smem, WaveStamp &stamp) {
-    const BsBlockDesc bd = it.blocks[g];
-    if (bd.n_valid == 0 || !block_is_affine(it, bd)) return;  // workgroup uniform
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, k = lane & 31, h = lane >> 5;
-    const int nslots = a.nslots, RS = nslots | 1, RS4 = 4 * RS, F4 = 4 * nslots, TS = bs_affine_ts(nslots), WS = bs_affine_ws(nslots);
-    const int n = bd.n_valid;
-    float4 *tile = smem;                                              // [kB][RS] the user rows, zero past the block's end
-    const float *tilef = reinterpret_cast<const float *>(tile);
-    float *Ms = reinterpret_cast<float *>(smem + kB * RS);            // M11 | M21 | M22, rows of kMS floats
-    float *Ws = Ms + 3 * kH * kMS;                                    // [kB][WS]
-    float *tab = Ws + kB * WS;                                        // a^d | c^d, d in [0, 64)
-    float *basev = tab + 2 * kB;                                      // [kB] r - gb - ub, 0 past the end of a short block
-    {
-        const uint64_t val = it.vals[bd.pos0 + min(lane, n - 1)];
-        const int x = static_cast<int>(val >> 32);
-        // the rows: 8 per wavefront, 8 lanes x 16 bytes per row piece; every load unconditional at a clamped address
-        const int rsub = lane >> 3, cs = lane & 7, row = 8 * wave + rsub;
-        const int xr = __shfl(x, row);
-        const float4 *src = reinterpret_cast<const float4 *>(a.P + static_cast<size_t>(xr) * a.ldp);
-        float4 v[4];
-        const float *rec = it.Mbuf + static_cast<size_t>(g) * kBsRecFloats;
-        f32x4 mq[2];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = src[min(8 * c + cs, nslots - 1)];
-        // the record: 768 pieces of 16 bytes for the three tiles, 16 for the base errors
-#pragma unroll
-        for (int q = 0; q < 2; ++q) mq[q] = *reinterpret_cast<const f32x4 *>(rec + 4 * min(tid + 512 * q, 3 * 256 + 15));
-        const float ta = it.tables[kTabApow + (tid & 63)], tc = it.tables[kTabCpow + (tid & 63)];
-        for (int c0 = 0; c0 < nslots; c0 += 32) {
-            if (c0 > 0) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = src[min(c0 + 8 * c + cs, nslots - 1)];
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int slot = c0 + 8 * c + cs;
-                if (slot < nslots) tile[row * RS + slot] = row < n ? v[c] : zero4();
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int piece = tid + 512 * q;
-            if (piece < 3 * 256) {
-                const int t = piece >> 8, r = (piece >> 3) & 31, c4 = piece & 7;
-                *reinterpret_cast<f32x4 *>(Ms + (t * kH + r) * kMS + 4 * c4) = mq[q];
-            } else if (piece < 3 * 256 + 16) {
-                *reinterpret_cast<f32x4 *>(basev + 4 * (piece - 3 * 256)) = mq[q];
-            }
-        }
-        if (tid < kB) tab[tid] = ta, tab[kB + tid] = tc;
-    }
-    __syncthreads();
-    stamp.mark(it, 0);
-    if (wave < 4) {
-        const int jc = 32 * wave + k, jcc = min(jc, F4 - 1);
-        const bool is_p = jc < F4, is_c = jc == F4, is_r = jc == F4 + 1;
-        float bl[16], bu[16], m11[16], m21[16], m22[16];
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            const float4 x11 = *reinterpret_cast<const float4 *>(Ms + k * kMS + 16 * h + 4 * t4);
-            const float4 x21 = *reinterpret_cast<const float4 *>(Ms + (kH + k) * kMS + 16 * h + 4 * t4);
-            const float4 x22 = *reinterpret_cast<const float4 *>(Ms + (2 * kH + k) * kMS + 16 * h + 4 * t4);
-            m11[4 * t4] = x11.x, m11[4 * t4 + 1] = x11.y, m11[4 * t4 + 2] = x11.z, m11[4 * t4 + 3] = x11.w;
-            m22[4 * t4] = x22.x, m22[4 * t4 + 1] = x22.y, m22[4 * t4 + 2] = x22.z, m22[4 * t4 + 3] = x22.w;
-            m21[4 * t4] = x21.x, m21[4 * t4 + 1] = x21.y, m21[4 * t4 + 2] = x21.z, m21[4 * t4 + 3] = x21.w;
-        }
-#pragma unroll
-        for (int s4 = 0; s4 < 16; s4 += 4) {
-            const float4 al = *reinterpret_cast<const float4 *>(tab + 16 * h + s4), au = *reinterpret_cast<const float4 *>(tab + kH + 16 * h + s4);
-            const float4 cl = *reinterpret_cast<const float4 *>(tab + kB + 16 * h + s4), cu = *reinterpret_cast<const float4 *>(tab + kB + kH + 16 * h + s4);
-            const float4 rl = *reinterpret_cast<const float4 *>(basev + 16 * h + s4), ru = *reinterpret_cast<const float4 *>(basev + kH + 16 * h + s4);
-            const float alv[4] = {al.x, al.y, al.z, al.w}, auv[4] = {au.x, au.y, au.z, au.w};
-            const float clv[4] = {cl.x, cl.y, cl.z, cl.w}, cuv[4] = {cu.x, cu.y, cu.z, cu.w};
-            const float rlv[4] = {rl.x, rl.y, rl.z, rl.w}, ruv[4] = {ru.x, ru.y, ru.z, ru.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kl = 16 * h + s4 + u, ku = kH + kl;
-                float pl = tilef[kl * RS4 + jcc], pu = tilef[ku * RS4 + jcc];
-                asm volatile("" : "+v"(pl), "+v"(pu));  // loaded here, not inside the selects below
-                const float gl = kl < n ? clv[u] : 0.f, gu = ku < n ? cuv[u] : 0.f;
-                bl[s4 + u] = is_p ? pl * alv[u] : is_c ? gl : is_r ? rlv[u] : 0.f;
-                bu[s4 + u] = is_p ? pu * auv[u] : is_c ? gu : is_r ? ruv[u] : 0.f;
-            }
-        }
-        f32x16 wt, wb;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) wt[i] = wb[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            wt = __builtin_amdgcn_mfma_f32_32x32x2f32(m11[s], bl[s], wt, 0, 0, 0);
-            wb = __builtin_amdgcn_mfma_f32_32x32x2f32(m21[s], bl[s], wb, 0, 0, 0);
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) wb = __builtin_amdgcn_mfma_f32_32x32x2f32(m22[s], bu[s], wb, 0, 0, 0);
-        if (jc < WS) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {  // (columns past 4 nslots + 1: zeros)
-                const int r0 = acc_row(reg, h), r1 = kH + r0;
-                Ws[r0 * WS + jc] = wt[reg];
-                Ws[r1 * WS + jc] = wb[reg];
-            }
-        }
-    }
-    __syncthreads();
-    stamp.mark(it, 1);
-    // W leaves from LDS as it lies there, 16 bytes per lane (phase 3 reads it: the launch boundary publishes it)
-    float *Wg = it.Wbuf + static_cast<size_t>(g) * bs_affine_w_floats(nslots);
-    for (int idx = tid; idx < kB * (WS >> 2); idx += 512) reinterpret_cast<f32x4 *>(Wg)[idx] = reinterpret_cast<const f32x4 *>(Ws)[idx];
-    // T': this wavefront's 32 rows x 64 columns; eight groups of four contraction steps, the LDS reads of group gq + 1 issued
-    // before the products of group gq (the compiler on its own read every B operand right before its product)
-    {
-        const int wr = wave >> 1, J0 = 2 * (wave & 1);
-        const int i = 32 * wr + k, ic = min(i, F4 - 1);
-        const float fp = i < F4 ? 1.f : 0.f, fc = i == F4 ? 1.f : 0.f;
-        f32x16 acc[2];
-#pragma unroll
-        for (int J = 0; J < 2; ++J)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[J][r] = 0.f;
-        float pv[2][4], ta[2][4], tc[2][4], bv[2][2][4];
-        auto read_group = [&](int buf, int gq) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kl = kH * (gq >> 2) + 16 * h + 4 * (gq & 3) + u;
-                const int back = max(n - 1 - kl, 0);
-                pv[buf][u] = tilef[kl * RS4 + ic];
-                ta[buf][u] = tab[back];
-                tc[buf][u] = tab[kB + back];
-#pragma unroll
-                for (int J = 0; J < 2; ++J) bv[buf][J][u] = Ws[kl * WS + 32 * (J0 + J) + k];  // past column WS: the next row, never stored
-            }
-        };
-        auto products = [&](int buf, int gq) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kl = kH * (gq >> 2) + 16 * h + 4 * (gq & 3) + u;
-                // H^T[i][kl] = p_kl[i] a^back (i a column of the row), c^back (i the bias), 0 (past the state)
-                const float av = (pv[buf][u] * ta[buf][u]) * fp + tc[buf][u] * (kl < n ? fc : 0.f);
-#pragma unroll
-                for (int J = 0; J < 2; ++J) acc[J] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[buf][J][u], acc[J], 0, 0, 0);
-            }
-        };
-        read_group(0, 0);
-#pragma unroll 1
-        for (int gq = 0; gq < 8; gq += 2) {  // (not unrolled: eight groups' addresses at once cost 70 spilled registers)
-            read_group(1, gq + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            products(0, gq);
-            __builtin_amdgcn_sched_barrier(0);
-            read_group(0, min(gq + 2, 7));
-            __builtin_amdgcn_sched_barrier(0);
-            products(1, gq + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stamp.mark(it, 2);
-        // whole accumulator tiles (the buffer has room for 128 rows), a row of 32 columns per half wavefront and store
-        float *Tg = it.Tbuf + static_cast<size_t>(g) * bs_affine_t_floats(nslots);
-#pragma unroll
-        for (int J = 0; J < 2; ++J) {
-            const int col = 32 * (J0 + J) + k;
-            if (col < TS) {
-                float *dst = Tg + static_cast<size_t>(32 * wr + 4 * h) * TS + col;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) store_through(dst + (8 * (reg >> 2) + (reg & 3)) * TS, acc[J][reg]);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's part of T' has left the CU ...
-    __syncthreads();                                   // ... and so has everybody else's: the block may be announced
-    if (tid == 0) __hip_atomic_store(it.aff_flag + g, it.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    stamp.mark(it, 3);
-    stamp.done(it, 6, g * 8 + wave);
-}
-
-// ---- phase 2, long chains: the affine form ----------------------------------------------------------------------------
-// Phase 1 left T' of every block of the chain (bs_gram_kernel): the block maps the state s = (item row, item bias) to
-// Lambda^n s - lr T' (s, -1).  Two wavefronts apply it (thread i < 128: row i of T' against the state, both read from LDS;
-// the state is double buffered, so ONE barrier per block hands over both the new state and the ring slot), six wavefronts stream
-// the T' blocks (contiguous, (4 nslots + 1) x bs_affine_ts floats, 43.6 KB at f = 100) into a ring of two LDS slots,
-// kDepthA blocks in flight in their registers.  No meeting point inside a block.  The start state of every block goes to
-// phase 3, which recovers the block's errors from it (e = -W (s0, -1)).
-constexpr int kRingA = 2, kDepthA = 4;
-constexpr int kAffApply = 128, kAffLoaders = 512 - kAffApply;
-__host__ __device__ inline int affine_block_f4(int nslots) { return (4 * nslots + 1) * ((nslots + 1) | 1); }
-// the state in LDS: (s, -1, 0 ...) padded with zeros to whole chunks of four 16-byte columns, two chunks past the last one (the
-// apply loop's look-ahead reads them unconditionally: a predicated LDS read becomes a branch with a full wait behind it)
-__host__ __device__ inline int affine_state_f4(int nslots) { return 4 * (((((nslots + 1) | 1) + 3) >> 2) + 2); }
-__host__ __device__ inline size_t affine_lds_bytes(int nslots) {
-    return (static_cast<size_t>(kRingA) * affine_block_f4(nslots) + 2 * affine_state_f4(nslots) + 1) * 16;
-}
-
-// a loader thread's share of block t: float4 numbers lt, lt + kAffLoaders, ... (written as pack expansions: the stages must
-// stay in registers, and a loop the compiler decides not to unroll would put them in scratch memory).  Every load is
-// unconditional at a clamped address, see the loader of the other chains.
-template <int N, int... I>
-__device__ __forceinline__ void aff_issue(f32x4 (&st)[N], const float4 *Tsrc, int t, int nblk, int stride4, int total4, int lt,
-                                          std::integer_sequence<int, I...>) {
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(Tsrc + static_cast<size_t>(min(t, nblk - 1)) * stride4);
-    ((st[I] = src[min(lt + kAffLoaders * I, total4 - 1)]), ...);
-}
-template <int N, int... I>
-__device__ __forceinline__ void aff_commit(const f32x4 (&st)[N], float4 *dst4, int total4, int lt, std::integer_sequence<int, I...>) {
-    f32x4 *dst = reinterpret_cast<f32x4 *>(dst4);
-    ((lt + kAffLoaders * I < total4 ? (void)(dst[lt + kAffLoaders * I] = st[I]) : (void)0), ...);
-}
-
-template <int SW>
-__device__ __forceinline__ void bs_affine_chain(const SgdArgs &a, const BsIteration &it, const BsChainDesc &cd, int chain, float4 *smem,
-                                                WaveStamp &stamp) {
-    constexpr int kNs = 4 * SW < 31 ? 4 * SW : 31;
-    constexpr int NA = ((4 * kNs + 1) * ((kNs + 1) | 1) + kAffLoaders - 1) / kAffLoaders;  // float4 per loader thread and block
-    using Seq = std::make_integer_sequence<int, NA>;
-    const int nslots = a.nslots, F4 = 4 * nslots, R = F4 + 1, n4 = (nslots + 1) | 1;
-    const int total4 = R * n4;
-    const int len = cd.len, nblk = (len + kB - 1) / kB, g0 = cd.blk0;
-    const int n_intervals = (nblk + kDepthA - 1) / kDepthA * kDepthA;
-    const int tid = threadIdx.x;
-    const int stride4 = 128 * n4;  // a block's T' in memory: room for 128 rows
-    const float4 *Tsrc = reinterpret_cast<const float4 *>(it.Tbuf) + static_cast<size_t>(g0) * stride4;
-    // The maps are being built by other workgroups of this launch (affine_build_block) and announced block by block (bounded
-    // waits).  ONE acquire per wavefront, at once: it drops what this CU / XCD still holds of the last iteration's T'; nothing
-    // reads a block's lines again before its flag has been seen.  The loaders need the first five blocks to fill their pipeline;
-    // the appliers look at the flags of ALL blocks (and then wait for the state) before the first barrier, behind which the
-    // loaders ask for the later blocks.
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    auto await_map = [&](int m) {  // m < nblk
-        const unsigned long long t0 = wall_clock64();
-        unsigned polls = 0;
-        while (ld_agent(it.aff_flag + g0 + m) != it.epoch) {
-            __builtin_amdgcn_s_sleep(8);
-            if ((++polls & 63u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
-                __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    };
-    if (tid >= kAffApply) {
-        const int lt = tid - kAffApply;
-        if ((tid & 63) <= kDepthA) await_map(min(tid & 63, nblk - 1));
-        static_assert(kDepthA == 4 && kRingA == 2, "the loop below is written out for four stages and two slots");
-        f32x4 s0[NA], s1[NA], s2[NA], s3[NA];  // four blocks in flight
-        aff_issue(s0, Tsrc, 0, nblk, stride4, total4, lt, Seq{});
-        aff_issue(s1, Tsrc, 1, nblk, stride4, total4, lt, Seq{});
-        aff_issue(s2, Tsrc, 2, nblk, stride4, total4, lt, Seq{});
-        aff_issue(s3, Tsrc, 3, nblk, stride4, total4, lt, Seq{});
-        aff_commit(s0, smem, total4, lt, Seq{});  // block 0
-        aff_issue(s0, Tsrc, 4, nblk, stride4, total4, lt, Seq{});
-        __syncthreads();
-        stamp.mark(it, 0);
-        for (int m0 = 0; m0 < n_intervals; m0 += 4) {  // while block m is applied: block m + 1 into the other slot
-            if (m0 == 8) stamp.mark(it, 1);
-            if (m0 == 16) stamp.mark(it, 2);
-            if (m0 == 24) stamp.mark(it, 3);
-            aff_commit(s1, smem + total4, total4, lt, Seq{});
-            aff_issue(s1, Tsrc, m0 + 5, nblk, stride4, total4, lt, Seq{});
-            __syncthreads();
-            aff_commit(s2, smem, total4, lt, Seq{});
-            aff_issue(s2, Tsrc, m0 + 6, nblk, stride4, total4, lt, Seq{});
-            __syncthreads();
-            aff_commit(s3, smem + total4, total4, lt, Seq{});
-            aff_issue(s3, Tsrc, m0 + 7, nblk, stride4, total4, lt, Seq{});
-            __syncthreads();
-            aff_commit(s0, smem, total4, lt, Seq{});
-            aff_issue(s0, Tsrc, m0 + 8, nblk, stride4, total4, lt, Seq{});
-            __syncthreads();
-        }
-        stamp.done(it, 3, (it.n_hot + chain) * 4 + ((tid >> 6) & 3));
-        return;
-    }
-    __builtin_amdgcn_s_setprio(3);
-    const int i = tid;  // this thread's row of T' = its component of the state
-    const int y = cd.item;
-    const int SB = 4 * affine_state_f4(nslots);                       // floats per state buffer
-    float *sbuf = reinterpret_cast<float *>(smem + kRingA * total4);  // two buffers: (s, -1, 0 ...)
-    const int rc = min(i, R - 1);
-    // The state behind the chain's plain head comes from that workgroup through memory (solve_chain, head_only), one 8-byte
-    // granule {epoch, value} per component: every thread polls its own
-    for (int m = tid; m < nblk; m += kAffApply) await_map(m);
-    float s;
-    {
-        const unsigned long long *gr = it.hstate + static_cast<size_t>(chain) * 128 + min(i, F4);
-        const unsigned long long t0 = wall_clock64();
-        unsigned polls = 0;
-        unsigned long long v;
-        while (static_cast<unsigned>((v = ld_agent(gr)) >> 32) != it.epoch) {
-            __builtin_amdgcn_s_sleep(2);
-            if ((++polls & 255u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
-                __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        s = i <= F4 ? __uint_as_float(static_cast<unsigned>(v)) : 0.f;  // the item row, then the bias
-    }
-    for (int j = tid; j < 2 * SB; j += kAffApply) {  // both buffers: past the state the constant -1, then zeros
-        const int jj = j < SB ? j : j - SB;
-        if (jj > F4) sbuf[j] = jj == F4 + 1 ? -1.f : 0.f;
-    }
-    if (i < R) sbuf[i] = s;
-    const float lr = a.h.lr;
-    const int n_last = len - kB * (nblk - 1);
-    const float del_full = i < F4 ? it.tables[kTabAdel + kB] : it.tables[kTabCdel + kB];
-    const float del_last = i < F4 ? it.tables[kTabAdel + n_last] : it.tables[kTabCdel + n_last];
-    const int NC = (n4 + 3) >> 2;  // chunks of four 16-byte columns
-    __syncthreads();
-    stamp.mark(it, 0);
-    for (int m = 0; m < n_intervals; ++m) {
-        if (m == 8) stamp.mark(it, 1);
-        if (m == 16) stamp.mark(it, 2);
-        if (m == 24) stamp.mark(it, 3);
-        if (m < nblk) {  // workgroup uniform
-            const float del = m == nblk - 1 ? del_last : del_full;
-            if (i < F4) it.qstart[static_cast<size_t>(g0 + m) * a.ldq + i] = s;
-            if (i == F4) it.bstart[g0 + m] = s;
-            const float4 *row = smem + (m % kRingA) * total4 + rc * n4;
-            const float4 *sb4 = reinterpret_cast<const float4 *>(sbuf + (m & 1) * SB);
-            // packed pairs as they lie in the registers of a 16-byte LDS read: v_pk_fma_f32 without a register move
-            f32x2 acc_lo = {0.f, 0.f}, acc_hi = {0.f, 0.f};
-            f32x4 tv[2][4], sv[2][4];
-            const f32x4 *rowv = reinterpret_cast<const f32x4 *>(row), *sbv = reinterpret_cast<const f32x4 *>(sb4);
-            auto load = [&](int buf, int ch) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int c = 4 * ch + u;
-                    tv[buf][u] = rowv[min(c, n4 - 1)];
-                    sv[buf][u] = sbv[c];  // zeros past the state
-                }
-            };
-            auto fma4 = [&](int buf) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc_lo = fma2(lo2(tv[buf][u]), lo2(sv[buf][u]), acc_lo);
-                    acc_hi = fma2(hi2(tv[buf][u]), hi2(sv[buf][u]), acc_hi);
-                }
-            };
-            load(0, 0);
-            for (int ch = 0; ch < NC; ch += 2) {
-                load(1, ch + 1);  // past the last chunk: clamped addresses, zero weights
-                __builtin_amdgcn_sched_barrier(0);
-                fma4(0);
-                __builtin_amdgcn_sched_barrier(0);
-                load(0, ch + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                fma4(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const f32x4 acc = {acc_lo[0], acc_lo[1], acc_hi[0], acc_hi[1]};
-            const float t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-            s = i < R ? (s - del * s) - lr * t : 0.f;
-            if (i < R) sbuf[((m + 1) & 1) * SB + i] = s;  // the other buffer: nobody reads it in this interval
-        }
-        __syncthreads();
-    }
-    if (i < F4) a.Q[static_cast<size_t>(y) * a.ldq + i] = s;
-    if (i == F4) a.item_bias[y] = s;
-    stamp.done(it, 2, (it.n_hot + chain) * 4 + (tid >> 6));
-}
-
 // Eight wavefronts: four solvers (one per SIMD) and four loaders.
 //   loaders: stream the chain's blocks (64 user rows, the factor tiles, the base errors) into a ring of two LDS slots,
 //            kDepth blocks in flight in their registers; every load unconditional at a clamped address.
@@ -1095,12 +580,10 @@ __device__ __forceinline__ void bs_affine_chain(const SgdArgs &a, const BsIterat
 //            (the barrier is the one per block all eight wavefronts share: it hands the ring slot back to the loaders)
 //   One wavefront doing all of it issued ~500 instructions per block and took 1.35 us of the block's 1.8 us; the
 //   loaders alone sustain a block per 0.42 us (tools/build_variant.sh ablations, profiles/README.md).
-// SW: float4 slots per row quarter (4 * SW >= nslots).  CONC: the concurrent topology's hand-over (gate, records awaited block by
-// block, write-through stores, announced progress) -- compiled out of the default, sequential instantiation, which is the plain
-// chain: its registers and its loop are not paid for by a mode it does not run (with run-time branches: 256 registers, spills).
-template <int SW, bool CONC>
+// SW: float4 slots per row quarter (4 * SW >= nslots).
+template <int SW>
 __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration &it, float4 *bs_smem, WaveStamp &stamp, int chain,
-                                            const BsChainDesc &cd, bool head_only = false) {
+                                            const BsChainDesc &cd) {
     const int begin = cd.begin, len = cd.len;
     if (len <= 0) return;  // workgroup uniform
     const int nblk = (len + kB - 1) / kB;
@@ -1125,7 +608,7 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
 #pragma unroll
             for (int i = 0; i < NLT; ++i) s.rows[i] = (CU2REC_BS_ABLATE & 32) ? f32x4{0.01f, 0.01f, 0.01f, 0.01f} : row[min(tp + 4 * i, nslots - 1)];
         };
-        auto issue_rec = [&](Stage<NLT> &s, int t) {  // phase 1's record of the block: only behind the gate / the solvers' await_blocks
+        auto issue_rec = [&](Stage<NLT> &s, int t) {  // phase 1's record of the block
             const float *rec = it.Mbuf + static_cast<size_t>(g0 + min(t, nblk - 1)) * kBsRecFloats;
             const f32x4 *mg = reinterpret_cast<const f32x4 *>(rec);
 #pragma unroll
@@ -1158,11 +641,6 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
             uint64_t v[kDepth];
 #pragma unroll
             for (int t = 0; t < kDepth; ++t) v[t] = load_val(t);
-            // The gate: phase 1 has announced the records of the first kDepth + 2 blocks (await_blocks).  It also guards the USER
-            // ROWS: this launch starts as soon as the previous iteration's chains are through, while that iteration's phase 3
-            // and walked chains may still be writing rows -- phase 1 of this iteration runs behind them, so a row is final once
-            // a record of this iteration exists.  (Rows fetched in front of the gate: wrong results, caught by the tests.)
-            if (CONC) __syncthreads();
 #pragma unroll
             for (int t = 0; t < kDepth; ++t) issue(st[t], t, v[t]);
             commit(st[0], 0);
@@ -1182,7 +660,6 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
             uint64_t v[kDepth];
 #pragma unroll
             for (int t = 0; t < kDepth; ++t) v[t] = load_val(min(t, nblk - 1));
-            if (CONC) __syncthreads();  // the gate (see above)
 #pragma unroll
             for (int t = 0; t < kDepth; ++t)
                 if (t < nblk) issue(st[t], t, v[t]);
@@ -1195,7 +672,6 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
             }
         }
         stamp.done(it, 3, chain * 4 + ((tid >> 6) & 3));
-        if (CONC) __syncthreads();  // the chain is through (its solvers have stored the item row): LDS may be reused for the next one
         return;
     }
 
@@ -1232,35 +708,11 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
     const float lr = a.h.lr;
     const int kr = k & 31;
     const bool upper = k >= kH;
-    // what a live block makes this wavefront store for phase 3 (write-through stores the compiler does not count): the
-    // errors (wavefront 0) and its share of the start row, one instruction per pass that holds any slot of the row
-    int stores_per_block = w == 0 ? 1 : 0;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) stores_per_block += 8 * p < SW && w * SW + 8 * p < nslots ? 1 : 0;
-    // every load of the prologue is consumed HERE, in front of the loop: a value the compiler still counts as "in flight" at the
-    // loop's head would get its s_waitcnt vmcnt(0) inside the loop body, executed every block (see ld_agent_now)
-    if (CONC) {
-        asm volatile("" ::"v"(b));
-#pragma unroll
-        for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(q4[p]));
-    }
-    int ready = 0, ops_prev = 0;
-    // (the pipelined topology runs this instantiation for its announced progress and write-through stores; phase 1 is complete then,
-    // nothing to await)
-    if (CONC && w == 0 && it.concurrent) ready = await_blocks(it, g0, nblk, 0, kDepth + 2, k);
-    if (CONC) __syncthreads();  // the gate: the loaders start
     stamp.mark(it, 0);
     __syncthreads();  // block 0 is in the ring
     stamp.mark(it, 1);
-    unsigned long long *progress = it.chain_prog + static_cast<size_t>(chain) * kBsProgWords;
     for (int m = 0; m < n_intervals; ++m) {
         const bool live = m < nblk;  // workgroup uniform
-        // Blocks [0, m - 2) have left for phase 3: at the end of block m - 1 every solver wavefront waited for its stores of the
-        // blocks before m - 2 (not for the two youngest blocks': the latency of a write-through store stays off the chain),
-        // then came the barrier.
-        const bool publish = CONC && m >= 3 && m <= nblk + 2;
-        if (tid == 0 && publish) st_agent_u64(progress, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(m - 2));
-        const int ops_now = (live && !(CU2REC_BS_ABLATE & 1) ? stores_per_block : 0) + (w == 0 && publish ? 1 : 0);
         const int n = min(kB, len - kB * m);
         const float4 *tile = smem + (m % kRing) * S4;
         const float *Mt = reinterpret_cast<const float *>(tile + kB * RS);
@@ -1324,12 +776,12 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
         if (live) {
             const f32x4 e4 = lds4(epart + k);
             const float e = (e4.x + e4.y) + (e4.z + e4.w);
-            if (!(CU2REC_BS_ABLATE & 1) && w == 0) {  // the block's errors, four to a lane, write-through (phase 3 runs beside us)
+            if (!(CU2REC_BS_ABLATE & 1) && w == 0) {  // the block's errors, four to a lane, for phase 3
                 const float e0 = k < n ? e : 0.f;
                 const f32x4 e4v = {e0, dpp_move<0x55>(e0), dpp_move<0xAA>(e0), dpp_move<0xFF>(e0)};  // quad lanes 0..3
                 if ((k & 3) == 0) {
                     float *dst = it.ebuf + static_cast<size_t>(g0 + m) * kB + k;
-                    if (CONC) store_through(dst, e4v); else *reinterpret_cast<f32x4 *>(dst) = e4v;
+                    *reinterpret_cast<f32x4 *>(dst) = e4v;
                 }
             }
             // (C) the state the block leaves behind; its start state goes to phase 3
@@ -1343,9 +795,7 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
             for (int p = 0; p < NP; ++p) {  // lane (slot, group): sum over the group's 8 links of w_k P[k][slot]
                 const int sq = 8 * p + sl, slot = w * SW + sq;
                 const bool ok = sq < SW && slot < nslots;
-                if (!(CU2REC_BS_ABLATE & 1) && ok && kg == 0) {
-                    if (CONC) store_through(qdst + 4 * slot, q4[p]); else *reinterpret_cast<f32x4 *>(qdst + 4 * slot) = q4[p];
-                }
+                if (!(CU2REC_BS_ABLATE & 1) && ok && kg == 0) *reinterpret_cast<f32x4 *>(qdst + 4 * slot) = q4[p];
                 const float4 *colp = tile + (8 * kg) * RS + min(slot, nslots - 1);
                 f32x4 tb[8], wb[2];
 #pragma unroll
@@ -1373,40 +823,11 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
                 if (kg == 0 && sq < SW) *reinterpret_cast<f32x4 *>(qrow + slot) = q4[p];
             }
         }
-        // the records the loaders will ask for after the next barrier: block m + 2 + kDepth (see the loader's loop)
-        if (CONC) {
-            if (w == 0 && it.concurrent) ready = await_blocks(it, g0, nblk, ready, m + 3 + kDepth, k);
-            wait_all_but(ops_now + ops_prev);  // (never more than this wavefront really issued in the two blocks: see stores_per_block)
-            ops_prev = ops_now;
-        }
         __syncthreads();
         if (m == nblk / 2) stamp.mark(it, 2);
         if (m == nblk - 1) stamp.mark(it, 3);
     }
-    if (CONC) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        met += 4;
-        solvers_meet(meet, met, k);  // (the loaders have left: the workgroup barrier is not the solvers' alone any more)
-        if (tid == 0) st_agent_u64(progress, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(nblk));
-    }
-    if (head_only) {
-        // the chain goes on in the affine form in another workgroup (bs_affine_chain): row and bias go there through memory
-        // as 8-byte granules {epoch, value}: the data is the flag (no drain, no second store)
-        unsigned long long *hs = it.hstate + static_cast<size_t>(chain) * 128;
-        const unsigned long long tag = static_cast<unsigned long long>(it.epoch) << 32;
-        if (kg == 0) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int sq = 8 * p + sl, slot = w * SW + sq;
-                if (sq < SW && slot < nslots) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        __hip_atomic_store(hs + 4 * slot + c, tag | __float_as_uint(q4[p][c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        if (tid == 0) __hip_atomic_store(hs + 4 * nslots, tag | __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
+    {
         if (kg == 0) {
             f32x4 *qdst = reinterpret_cast<f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
 #pragma unroll
@@ -1418,7 +839,6 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
         if (tid == 0) a.item_bias[y] = b;
     }
     stamp.done(it, 2, chain * 4 + w);
-    if (CONC) __syncthreads();  // pairs with the loaders' last barrier
 }
 
 // ---- phase 2, the longest chains: the look-ahead form ---------------------------------------------------------------------------
@@ -1537,7 +957,7 @@ __device__ __forceinline__ void la_wait2(unsigned *sy, int word, unsigned target
 #endif
 }
 
-template <int NSM, bool PIPE>
+template <int NSM>
 __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIteration &it, float4 *smem, WaveStamp &stamp, int chain,
                                                 const BsChainDesc &cd) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1723,16 +1143,6 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
         __syncthreads();
         __builtin_amdgcn_s_setprio(2);
         unsigned long long wt[1] = {0};
-        // (pipelined topology: the start rows leave with write-through stores the compiler does not count, and this wavefront announces,
-        // a block late, how many blocks' worth of its stores are complete -- word 1 + c of the chain's progress record)
-        int my_stores = 0;
-#pragma unroll
-        for (int pp = 0; pp < NPW; ++pp) my_stores += 8 * (2 * pp + c) < nslots ? 1 : 0;
-        unsigned long long *progress = it.chain_prog + static_cast<size_t>(chain) * kBsProgWords + 1 + c;
-        if (PIPE) {
-#pragma unroll
-            for (int pp = 0; pp < NPW; ++pp) asm volatile("" ::"v"(q4[pp]));  // (the prologue's loads consumed in front of the loop)
-        }
         for (int i = 0; i < nblk; ++i) {
             const int n = min(kB, len - kB * i);
             const float adel_n = tab[kTabAdel + n];
@@ -1754,13 +1164,7 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
                 const int slot = 8 * (2 * pp + c) + sl;
                 const bool ok = slot < nslots;
                 // the row in front of block i: phase 3's
-                if (PIPE) {
-                    if (8 * (2 * pp + c) < nslots) {  // wavefront uniform: the instruction is issued exactly when the pass holds a slot
-                        if (ok && kg == 0) store_through(qdst + 4 * slot, q4[pp]);
-                    }
-                } else if (ok && kg == 0) {
-                    *reinterpret_cast<f32x4 *>(qdst + 4 * slot) = q4[pp];
-                }
+                if (ok && kg == 0) *reinterpret_cast<f32x4 *>(qdst + 4 * slot) = q4[pp];
                 f32x2 ulo = dup2(0.f), uhi = dup2(0.f);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -1781,16 +1185,6 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
                 if (ok && kg == 0) *reinterpret_cast<f32x4 *>(qbuf + ((i + 1) & 1) * kLaQ4 + slot) = q4[pp];
             }
             la_post(sy, kSyC0 + c, static_cast<unsigned>(i + 1));
-            // everything older than the stores of the two youngest blocks (and the announcement between them) is complete: blocks
-            // [0, i - 1) have left.  (Two blocks behind: the latency of a write-through store stays off the chain.)
-            if (PIPE && i > 1) {
-                wait_all_but(2 * my_stores + 1);
-                if (lane == 0) st_agent_u64(progress, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(i - 1));
-            }
-        }
-        if (PIPE) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) st_agent_u64(progress, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(nblk));
         }
         if (kg == 0) {
             f32x4 *qd = reinterpret_cast<f32x4 *>(a.Q + static_cast<size_t>(y) * a.ldq);
@@ -1843,7 +1237,6 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
         la_post(sy, kSyR, static_cast<unsigned>(i + 1));  // (the slot's reads are issued: LDS serves a wavefront in order)
     };
     take_record(0);
-    unsigned long long *eprog = it.chain_prog + static_cast<size_t>(chain) * kBsProgWords;
     for (int i = 0; i < nblk; ++i) {
         const int n = min(kB, len - kB * i);
         // t0 = N_i e_(i-1): this lane's row of the cross block against the errors of the block before (all 16 broadcast reads in
@@ -1892,7 +1285,7 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
         ebl[(i & 1) * kB + k] = e;
         wbuf[(i & 1) * kB + k] = k < n ? lr * tab[kTabApow + back] * e : 0.f;
         la_post(sy, kSyE, static_cast<unsigned>(i + 1));
-        if (PIPE) store_through(it.ebuf + static_cast<size_t>(g0 + i) * kB + k, e); else it.ebuf[static_cast<size_t>(g0 + i) * kB + k] = e;
+        it.ebuf[static_cast<size_t>(g0 + i) * kB + k] = e;
         if (i + 1 < nblk) take_record(i + 1);  // wavefront uniform
         // the item bias behind block i
         const float bs = row_sum16(k < n ? lr * tab[kTabCpow + back] * e : 0.f);
@@ -1900,14 +1293,6 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
         const float b_next = (b_cur - cdel_n * b_cur) + ((lane_value(bs, 0) + lane_value(bs, 16)) + (lane_value(bs, 32) + lane_value(bs, 48)));
         b_prev = b_cur;
         b_cur = b_next;
-        if (PIPE && i > 1) {  // the errors of blocks [0, i - 1) are in memory (pending at most: e, announcement, e): announce them
-            asm volatile("s_waitcnt vmcnt(3)");
-            if (k == 0) st_agent_u64(eprog, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(i - 1));
-        }
-    }
-    if (PIPE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (k == 0) st_agent_u64(eprog, static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(nblk));
     }
     stamp.span(1, wt[0]);
     stamp.span(2, wt[1]);
@@ -1916,21 +1301,17 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
     stamp.done(it, 2, chain * 4);
 }
 
-// Concurrent topology: the grid is at most half the CUs (workgroup g takes chains g, g + grid, ...: popularity ranks, so the long
-// chains come first and get a workgroup each): phase 1 runs at the same time and needs CUs of its own -- a chain's workgroup (2 x ~220
-// registers per SIMD, 80-160 KB of LDS) leaves no room for a phase-1 workgroup beside it, and chains waiting on every CU for
-// records nobody can produce would be a deadlock.  Sequential topology: one workgroup per chain.
-// The join with the side stream (and, pipelined topology, with phase 3): one thread of an extra workgroup in the LAST launch of the
-// iteration on the main stream.  It ends when the signal kernel queued behind this iteration's side kernel has run -- i.e. that kernel
-// is complete, its rows in memory -- so that the next iteration's phase 1, queued behind this launch, needs no event (a wait on one
-// costs the stream 2.5 us per iteration).  (The side kernel's workgroups counting THEMSELVES through, each behind an agent-scope
-// release of its rows, was tried in round 4: 9350 L2 write-backs per launch, the side kernel took 292 us instead of 46.)
+// The join with the side stream: one thread of an extra workgroup in the LAST launch of the iteration on the main stream (phase 3).
+// It ends when the signal kernel queued behind this iteration's side kernel has run -- i.e. that kernel is complete, its rows in
+// memory -- so that the next iteration's phase 1, queued behind this launch, needs no event (a wait on one costs the stream 2.5 us
+// per iteration).  (The side kernel's workgroups counting THEMSELVES through, each behind an agent-scope release of its rows, was
+// tried in round 4: 9350 L2 write-backs per launch, the side kernel took 292 us instead of 46.)
 // This wait guards DATA -- the next phase 1 reads rows the side kernel and phase 3 write -- so it gives up only when the GPU must be
 // taken for wedged: 15 x the bound of the other waits, 30 s by default; then the status word is set and the call reports it.
 __device__ __forceinline__ void await_iteration_end(const BsIteration &it) {
     const unsigned long long t0 = wall_clock64();
     unsigned polls = 0;
-    while ((it.side_seq && ld_agent(it.side_seq) < it.side_target) || (it.pipe && ld_agent(it.pipe_done) < it.pipe_target)) {
+    while (it.side_seq && ld_agent(it.side_seq) < it.side_target) {
         __builtin_amdgcn_s_sleep(8);
         if ((++polls & 63u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > 15ull * it.wait_ticks)) {
             __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1939,54 +1320,22 @@ __device__ __forceinline__ void await_iteration_end(const BsIteration &it) {
     }
 }
 
-// TOPO: 0 sequential, 1 concurrent, 2 pipelined (the sequential grid; the chains announce their progress block by block for the phase 3
-// that runs beside them, and one more workgroup ends the launch when that phase 3 and the side stream are through).
-template <int SW, int TOPO>
+// One workgroup per hot chain: the look-ahead form for the leading chains (rows of at most kLaMaxSlots slots), the plain form for the rest.
+template <int SW>
 __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it) {
     extern __shared__ float4 bs_smem[];
     WaveStamp stamp(it);
-    if (TOPO == 1) {
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // "I hold my CU"
-        for (int chain = blockIdx.x; chain < it.n_hot; chain += gridDim.x) solve_chain<SW, true>(a, it, bs_smem, stamp, chain, it.chains[chain]);
-    } else if (static_cast<int>(blockIdx.x) < it.n_hot) {
-        if (it.gram_done && threadIdx.x == 0)  // (the side stream's gate lets the side kernel go once the chains hold their CUs)
-            __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int chain = blockIdx.x;
-        const BsChainDesc cd = it.chains[chain];
-        // a long chain's head only (see chain_is_affine); the form takes rows of at most 31 slots (bs_affine_supported): compiled
-        // out of the wider instantiations
-        if constexpr (SW <= 8) {
-            if (chain_is_lookahead(it, chain, cd)) {  // workgroup uniform
-                chain_lookahead<(4 * SW < kLaMaxSlots ? 4 * SW : kLaMaxSlots), TOPO == 2>(a, it, bs_smem, stamp, chain, cd);
-                return;
-            }
-        }
-        if constexpr (TOPO == 2) {
-            solve_chain<SW, true>(a, it, bs_smem, stamp, chain, cd);
-        } else {
-            bool head_only = false;
-            if constexpr (SW <= 8) head_only = cd.len > 0 && chain_is_affine(it, chain);  // workgroup uniform
-            solve_chain<SW, false>(a, it, bs_smem, stamp, chain, BsChainDesc{cd.begin, head_only ? it.aff_head * kB : cd.len, cd.blk0, cd.item}, head_only);
-        }
-    } else if (TOPO == 2) {
-        if (threadIdx.x == 0) {  // (blockIdx.x == n_hot: the join, see await_iteration_end)
-            __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            await_iteration_end(it);
-        }
-    } else {
-        const int g = static_cast<int>(blockIdx.x) - it.n_hot;
-        if constexpr (SW <= 8) {
-            if (g < it.aff_cap) {
-                affine_build_block(a, it, g, bs_smem, stamp);
-            } else if (g - it.aff_cap < it.aff_tails && chain_is_affine(it, g - it.aff_cap)) {  // workgroup uniform
-                const int chain = g - it.aff_cap;
-                const BsChainDesc cd = it.chains[chain];
-                const int head_links = it.aff_head * kB;
-                bs_affine_chain<SW>(a, it, BsChainDesc{cd.begin + head_links, cd.len - head_links, cd.blk0 + it.aff_head, cd.item}, chain,
-                                    bs_smem, stamp);
-            }
+    if (it.gram_done && threadIdx.x == 0)  // (the side stream's gate lets the side kernel go once the chains hold their CUs)
+        __hip_atomic_fetch_add(it.solve_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int chain = blockIdx.x;
+    const BsChainDesc cd = it.chains[chain];
+    if constexpr (SW <= 8) {
+        if (chain_is_lookahead(it, chain, cd)) {  // workgroup uniform
+            chain_lookahead<(4 * SW < kLaMaxSlots ? 4 * SW : kLaMaxSlots)>(a, it, bs_smem, stamp, chain, cd);
+            return;
         }
     }
+    solve_chain<SW>(a, it, bs_smem, stamp, chain, cd);
 }
 
 // ---- phase 3: the user side of every hot block ---------------------------------------------------------------------
@@ -1999,11 +1348,10 @@ __global__ __launch_bounds__(512) void bs_solve_kernel(SgdArgs a, BsIteration it
 // 9 -- and the kernel's duration IS one wavefront's latency, every block's workgroup being resident at once.)
 constexpr int kUpdMaxWaves = (4 * kBsMaxSlots + 63) / 64;
 
-__device__ __forceinline__ void update_block(const SgdArgs &a, const BsIteration &it, int g, int nwaves, float *parts, WaveStamp &stamp) {
+__device__ __forceinline__ void update_block(const SgdArgs &a, const BsIteration &it, int g, int nwaves, WaveStamp &stamp) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) return;  // workgroup uniform
-    const bool affine = block_is_affine(it, bd);
     const bool mine = lane < bd.n_valid;  // lane l: link l
     // links past the end of a short block: the last link's row (finite, loaded, never stored) with e = 0
     const uint64_t val = it.vals[bd.pos0 + min(lane, bd.n_valid - 1)];
@@ -2011,59 +1359,8 @@ __device__ __forceinline__ void update_block(const SgdArgs &a, const BsIteration
     const float lr = a.h.lr;
     const int ncols = 4 * a.nslots;
     const int col = 64 * wave + lane, colc = min(col, ncols - 1);
-    // The chain's workgroup (bs_solve_kernel, ANOTHER launch running beside this one) announces how many of its blocks have left
-    // for phase 3: errors and start row of block m are there once the count has passed m (a look-ahead chain: the counts of the
-    // three wavefronts that store them).  Bounded wait; what the chain stored is then read with loads that are never served from a
-    // cache of this side (sc1: this XCD's L2 may still hold the block's lines of the iteration before).
-    const bool waits = (it.concurrent || it.pipe) && !(it.dbg & 8);  // workgroup uniform
-    if (waits) {
-        if (wave == 0) {
-            const int nwords = it.pipe && chain_is_lookahead(it, bd.chain, it.chains[bd.chain]) ? 3 : 1;
-            const unsigned long long *progress = it.chain_prog + static_cast<size_t>(bd.chain) * kBsProgWords + min(lane, nwords - 1);
-            const unsigned long long want = static_cast<unsigned long long>(it.epoch) << 32 | static_cast<unsigned>(bd.m + 1);
-            const unsigned long long t0 = wall_clock64();
-            unsigned polls = 0;
-            for (;;) {
-                const unsigned long long v = ld_agent(progress);
-                if (__all((v >> 32) == it.epoch && v >= want)) break;
-                if (it.pipe) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(48);  // (concurrent: hundreds of workgroups poll a few dozen words)
-                if ((++polls & 31u) == 0 && (ld_agent(it.status) != 0u || wall_clock64() - t0 > it.wait_ticks)) {
-                    if (lane == 0) __hip_atomic_store(it.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-    }
-    const float qs = waits ? __uint_as_float(ld_agent(reinterpret_cast<const unsigned *>(it.qstart + static_cast<size_t>(g) * a.ldq + colc)))
-                           : it.qstart[static_cast<size_t>(g) * a.ldq + colc];
-    float e_all;
-    if (affine) {
-        // e = -W (s0, -1): lane = link, this wavefront's share of the 16-byte columns, the shares summed through LDS
-        const int nslots = a.nslots;
-        const float4 *wrow = reinterpret_cast<const float4 *>(it.Wbuf + static_cast<size_t>(g) * bs_affine_w_floats(nslots)) + lane * (nslots + 1);
-        const float4 *q4 = reinterpret_cast<const float4 *>(it.qstart + static_cast<size_t>(g) * a.ldq);
-        const float b0 = it.bstart[g];
-        float part = 0.f;
-        for (int cc = wave; cc <= nslots; cc += nwaves) {
-            const float4 w4 = wrow[cc];
-            const float4 qv = q4[min(cc, nslots - 1)];
-            const float4 sv = cc < nslots ? qv : make_float4(b0, -1.f, 0.f, 0.f);
-            part = __builtin_fmaf(w4.x, sv.x, part);
-            part = __builtin_fmaf(w4.y, sv.y, part);
-            part = __builtin_fmaf(w4.z, sv.z, part);
-            part = __builtin_fmaf(w4.w, sv.w, part);
-        }
-        parts[wave * kB + lane] = part;
-        __syncthreads();
-        float sum = 0.f;
-        for (int w = 0; w < nwaves; ++w) sum += parts[w * kB + lane];
-        e_all = -sum;
-        if (wave == 0) it.ebuf[static_cast<size_t>(g) * kB + lane] = mine ? e_all : 0.f;  // for the record (tests read the errors back)
-    } else {
-        e_all = waits ? __uint_as_float(ld_agent(reinterpret_cast<const unsigned *>(it.ebuf + static_cast<size_t>(g) * kB + lane)))
-                      : it.ebuf[static_cast<size_t>(g) * kB + lane];
-    }
+    const float qs = it.qstart[static_cast<size_t>(g) * a.ldq + colc];
+    const float e_all = it.ebuf[static_cast<size_t>(g) * kB + lane];
     const float e = mine ? e_all : 0.f;
     stamp.fine(it, 0);  // user ids
     float p[kB];
@@ -2101,52 +1398,23 @@ __device__ __forceinline__ void update_block(const SgdArgs &a, const BsIteration
     stamp.done(it, 4, g * nwaves + wave);
 }
 
-// One workgroup per block (sequential and concurrent topologies).
+// One workgroup per block.
 __global__ __launch_bounds__(64 * kUpdMaxWaves) void bs_update_kernel(SgdArgs a, BsIteration it, int nwaves) {
-    __shared__ float parts[kUpdMaxWaves * kB];
     const int g = blockIdx.x;
     WaveStamp stamp(it);
     if (g == it.max_blocks) {  // the extra workgroup of the launch (side_seq set)
         if (threadIdx.x == 0) await_iteration_end(it);
         return;
     }
-    update_block(a, it, g, nwaves, parts, stamp);
-}
-
-// Pipelined topology: a grid of persistent workgroups beside phase 2, block order[j] to workgroup j mod grid.  Every wait is bounded
-// and every workgroup visits a fixed list of blocks: the grid drains whatever phase 2 does.
-__global__ __launch_bounds__(64 * kUpdMaxWaves) void bs_update_pipe_kernel(SgdArgs a, BsIteration it, int nwaves) {
-    __shared__ float parts[kUpdMaxWaves * kB];
-    WaveStamp stamp(it);
-    for (int j = blockIdx.x; j < it.max_blocks; j += gridDim.x) {
-        stamp.restart(it);
-        update_block(a, it, it.order[j], nwaves, parts, stamp);
-    }
-    // this workgroup's rows are on their way: the count is released behind them (the waiting workgroup of phase 2's launch reads it)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (every wavefront's stores complete in front of the barrier)
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(it.pipe_done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    update_block(a, it, g, nwaves, stamp);
 }
 
 template <int SW>
 void launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
-    size_t lds = std::max(solve_lds_bytes(a.nslots, SW),
-                          it.aff_min_blocks > 0 ? std::max(affine_lds_bytes(a.nslots), affine_build_lds_bytes(a.nslots)) : static_cast<size_t>(0));
+    size_t lds = solve_lds_bytes(a.nslots, SW);
     if (it.la_ranks > 0) lds = std::max(lds, la_lds_bytes(a.nslots));
-    if (it.concurrent) {
-        ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, 1>));
-        hipLaunchKernelGGL((bs_solve_kernel<SW, 1>), dim3(bs_solve_grid(it.n_hot)), dim3(512), lds, stream, a, it);
-    } else if (it.pipe) {
-        if constexpr (SW <= 8) {  // (the wider rows' chains spill in the form that announces its progress: ordered.hip does not ask for it)
-            ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, 2>));
-            hipLaunchKernelGGL((bs_solve_kernel<SW, 2>), dim3(it.n_hot + 1), dim3(512), lds, stream, a, it);
-        } else {
-            fail(CU2REC_EINVAL, "the pipelined topology is compiled for rows of at most 32 float4 slots");
-        }
-    } else {
-        ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW, 0>));
-        hipLaunchKernelGGL((bs_solve_kernel<SW, 0>), dim3(it.n_hot + (it.aff_min_blocks > 0 ? it.aff_cap + it.aff_tails : 0)), dim3(512), lds, stream, a, it);
-    }
+    ensure_max_dynamic_lds(reinterpret_cast<const void *>(bs_solve_kernel<SW>));
+    hipLaunchKernelGGL((bs_solve_kernel<SW>), dim3(it.n_hot), dim3(512), lds, stream, a, it);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess)
         fail(CU2REC_EHIP, std::string("bs_solve_kernel launch failed: ") + hipGetErrorString(err) + " (SW " + std::to_string(SW) +
@@ -2247,17 +1515,15 @@ int bs_compute_units() {
     return cus[dev];
 }
 
-int bs_solve_grid(int n_hot) { return std::max(1, std::min(n_hot, bs_compute_units() / 2)); }
-
 void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream) {
     hipLaunchKernelGGL(bs_tables_kernel, dim3(1), dim3(192), 0, stream, h, tables);
 }
 
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,
                     const int *item_of_rank, int *chain_begin, BsChainDesc *chains, BsBlockDesc *blocks, int *walk_begin,
-                    hipStream_t stream, size_t stride, bool batch_keys, int *order) {
+                    hipStream_t stream, size_t stride) {
     hipLaunchKernelGGL(bs_plan_kernel, dim3(n_batch), dim3(256), 0, stream, keys, n_active, n_hot, item_bits, max_blocks,
-                       item_of_rank, chain_begin, chains, blocks, walk_begin, stride, batch_keys ? 1 : 0, order);
+                       item_of_rank, chain_begin, chains, blocks, walk_begin, stride);
 }
 
 void bs_launch_gram(const SgdArgs &a, const BsIteration &it, hipStream_t stream, hipEvent_t stop) {
@@ -2324,13 +1590,6 @@ void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream
     else if (sw <= 12) launch_solve<12>(a, it, stream);
     else if (sw <= 16) launch_solve<16>(a, it, stream);
     else fail(CU2REC_EUNSUPPORTED, "block-solve mode is compiled for n_factors <= 256");
-}
-
-void bs_launch_update_pipe(const SgdArgs &a, const BsIteration &it, int grid, hipStream_t stream) {
-    if (it.n_hot <= 0 || it.max_blocks <= 0 || grid <= 0) return;
-    const int nwaves = (4 * a.nslots + 63) / 64;
-    hipLaunchKernelGGL(bs_update_pipe_kernel, dim3(grid), dim3(64 * nwaves), 0, stream, a, it, nwaves);
-    CU2REC_HIP(hipGetLastError());
 }
 
 void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {

@@ -25,7 +25,6 @@ namespace {
 
 hipStream_t as_stream(void *s) { return static_cast<hipStream_t>(s); }
 
-std::atomic<int> g_hogwild_block{1};  // updates per user per Hogwild launch (cu2rec_hogwild_iters_per_launch)
 
 void check_ld(int ld, int n_factors, const char *what) {
     if (ld < n_factors || (ld & 3) != 0)
@@ -124,7 +123,7 @@ void sgd_update(const int *indptr, const int *indices, const float *data, int n_
         // point where every user's update of iteration i is visible to iteration i+1
         // frozen items (is_train == false, predict.cu:105,126): no update crosses users, so the whole call is ONE launch
         // with every user's row in registers for all its iterations -- the same results as one launch per iteration
-        const int block = update_items ? std::max(1, g_hogwild_block.load()) : n_iters;
+        const int block = update_items ? 1 : n_iters;
         // the same iterations in ONE persistent launch (grid barrier where the kernel boundary was, user rows
         // resident in registers) whenever the rows fit and the policy allows it: resident.hip
         // (n_cols > 0: in a resident launch users without ratings read item row 0 and write to a sink)
@@ -495,12 +494,6 @@ int cu2rec_sgd_update_pingpong(const int *indptr, const int *indices, const floa
     });
 }
 
-int cu2rec_hogwild_iters_per_launch(int k) {
-    const int prev = g_hogwild_block.load();
-    if (k >= 1) g_hogwild_block.store(k);
-    return prev;
-}
-
 int cu2rec_hogwild_resident(int policy) { return resident_policy(policy); }
 
 int cu2rec_hogwild_resident_refusals(void) { return resident_refusals(); }
@@ -568,10 +561,7 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
 }
 
 float cu2rec_blocksolve_min_rate(float rate) { return blocksolve_min_rate(rate); }
-int cu2rec_blocksolve_affine_blocks(int blocks) { return blocksolve_affine_blocks(blocks); }
-int cu2rec_blocksolve_affine_head(int blocks) { return blocksolve_affine_head(blocks); }
 int cu2rec_blocksolve_lookahead_blocks(int blocks) { return blocksolve_lookahead_blocks(blocks); }
-int cu2rec_ordered_persistent_launches(void) { return ordered_persistent_launches(); }
 
 int cu2rec_csr_blocksolve_items(const cu2rec_csr *train) {
     int n = -1;

@@ -1,7 +1,7 @@
 // The grid-wide barrier of the persistent launches (resident.hip: Hogwild with the user rows in registers; ordered.hip: the
 // ordered walk of a small set, all iterations of a batch in one launch): XCD-hierarchical, split in two halves, every spin bounded.
 // MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility" ("barrier-xcd").  The functions take any
-// argument block with .words (the barrier block below, zeroed before the launch), .status (set by a wait that gave up) and .local.
+// argument block with .words (the barrier block below, zeroed before the launch) and .status (set by a wait that gave up).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -26,8 +26,7 @@ constexpr int kWCensusTop = kLine;                        // workgroups that hav
 constexpr int kWCensus = 2 * kLine;                       // [x]: workgroups on XCD x
 constexpr int kWArrive = kWCensus + kMaxXcc * kLine;      // [x]: arrivals on XCD x, summed over phases
 constexpr int kWGen = kWArrive + kMaxXcc * kLine;         // [x]: last phase XCD x may leave
-constexpr int kWTarget = kWGen + kMaxXcc * kLine;         // single-XCD launches: 1 + the XCD that runs them (workgroup 0's)
-constexpr int kBarrierWords = kWTarget + kLine;
+constexpr int kBarrierWords = kWGen + kMaxXcc * kLine;
 
 struct BarrierShared {  // per workgroup, in LDS; written by thread 0 only
     int xcc, n_mine, n_xcds, leader, ok;
@@ -63,9 +62,7 @@ __device__ __forceinline__ void barrier_census(const RA &ra, BarrierShared *bs) 
     // not overtake the first, which sits on another cache line), and a reader that has seen the full top count takes an
     // ACQUIRE before it reads the per-XCD counts.  With two relaxed adds a workgroup could see "everybody has arrived"
     // while the last per-XCD add was still in flight, undercount its XCD and open the barrier early.
-    const unsigned mine = __hip_atomic_fetch_add(ra.words + kWCensus + xcc * kLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ra.local && blockIdx.x == 0)  // (relaxed: ordered in front of the release below like the per-XCD count)
-        __hip_atomic_store(ra.words + kWTarget, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ra.words + kWCensus + xcc * kLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(ra.words + kWCensusTop, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     bs->ok = spin_until(ra.words + kWCensusTop, gridDim.x, ra.status) ? 1 : 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -74,12 +71,6 @@ __device__ __forceinline__ void barrier_census(const RA &ra, BarrierShared *bs) 
     bs->xcc = static_cast<int>(xcc);
     bs->n_mine = static_cast<int>(ld_relaxed(ra.words + kWCensus + xcc * kLine));
     bs->n_xcds = n_xcds;
-    bs->part = 1;
-    bs->index = static_cast<int>(mine);
-    if (ra.local) {  // the barrier is that of ONE XCD from here on: its workgroups, numbered in the order they reported
-        bs->part = ld_relaxed(ra.words + kWTarget) == xcc + 1u ? 1 : 0;
-        bs->n_xcds = 1;
-    }
 }
 
 // Grid barrier, split in two so that work which does not depend on other workgroups (the next iteration's sample
@@ -96,9 +87,8 @@ __device__ __forceinline__ void barrier_arrive(const RA &ra, unsigned phase, Bar
                                                     __HIP_MEMORY_SCOPE_AGENT);
         const bool leader = old + 1 == phase * static_cast<unsigned>(bs->n_mine);
         if (leader) {
-            if (!(CU2REC_BARRIER_ABLATE & 64) && !ra.local)             // 64: timing only, no L2 write-back
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines (a single-XCD
-                                                                    // launch shares ONE L2: nothing to write back)
+            if (!(CU2REC_BARRIER_ABLATE & 64))                        // 64: timing only, no L2 write-back
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write back this XCD's dirty L2 lines
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the compiler may drop its own wait here)
             __hip_atomic_fetch_add(ra.words + kWTop, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -131,12 +121,6 @@ __device__ __forceinline__ bool barrier_wait(const RA &ra, unsigned phase, Barri
     return bs->ok != 0;
 }
 
-
-struct Args {  // the plain argument block
-    unsigned *words;
-    unsigned *status;
-    int local;
-};
 
 }  // namespace gridbar
 }  // namespace cu2rec

@@ -16,9 +16,7 @@
 //   2. stable LSB radix sort of the (key, val) pairs, every iteration a segment of its own (hipCUB/rocPRIM
 //      DeviceSegmentedRadixSort; stability keeps users ascending inside a chain).  Afterwards iteration b occupies
 //      [b * n_rows, b * n_rows + n_active), chains are runs of equal keys, and because keys carry the item's popularity
-//      RANK, the longest chains come first.  (The first form -- one thread per sample, keys b << item_bits | rank, ONE sort
-//      of the whole batch, iteration b at [b * n_active, ...) -- is kept behind CU2REC_SCHED_KEYS_TILE=0 /
-//      CU2REC_SCHED_SEGMENTED=0: what it cost the iterations running beside it is in DESIGN.md section 4.)
+//      RANK, the longest chains come first.
 //   3. sgd_ordered_kernel, one launch per iteration (the kernel boundary carries the P-row dependency from
 //      iteration b to b+1).  The item row and item bias stay in registers for a whole chain (read and written once
 //      per chain, not once per update).  Two block roles:
@@ -52,8 +50,6 @@
 #include "ordered.hpp"
 #include "sampler.hpp"
 #include "sgd_device.hpp"
-#include "grid_barrier.hpp"
-#include "resident.hpp"
 
 namespace cu2rec {
 
@@ -76,32 +72,6 @@ using SegSortConfig = rocprim::segmented_radix_sort_config<8, rocprim::kernel_co
 
 constexpr int kHotChains = 256;  // most popular items: their chains run in the two-wave form (run_hot_block_duo)
 
-__global__ __launch_bounds__(kBlock) void schedule_keys_kernel(const int *__restrict__ indptr,
-                                                               const int *__restrict__ indices,
-                                                               const float *__restrict__ data,
-                                                               const int *__restrict__ item_rank, int n_rows,
-                                                               int n_batch, int item_bits, uint32_t sentinel,
-                                                               uint64_t seed, uint64_t iter0, int user_offset,
-                                                               uint32_t *__restrict__ keys, uint64_t *__restrict__ vals, int batch_keys) {
-    const size_t total = static_cast<size_t>(n_rows) * n_batch;
-    for (size_t idx = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; idx < total;
-         idx += static_cast<size_t>(gridDim.x) * kBlock) {
-        const int b = static_cast<int>(idx / n_rows);
-        const int x = static_cast<int>(idx - static_cast<size_t>(b) * n_rows);
-        const int low = indptr[x], high = indptr[x + 1];
-        uint32_t key = sentinel;
-        uint64_t val = 0;
-        if (low != high) {
-            const int y_i = sampler_index(seed, static_cast<uint64_t>(user_offset + x), iter0 + b, low, high);
-            const int y = indices[y_i];
-            key = (batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u) | static_cast<uint32_t>(item_rank[y]);
-            val = (static_cast<uint64_t>(static_cast<uint32_t>(x)) << 32) | __float_as_uint(data[y_i]);
-        }
-        keys[idx] = key;
-        vals[idx] = val;
-    }
-}
-
 // first position in keys[0, n) whose key is >= target
 __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys, int n, uint32_t target) {
     int lo = 0, hi = n;
@@ -112,10 +82,9 @@ __device__ __forceinline__ int lower_bound_key(const uint32_t *__restrict__ keys
     return lo;
 }
 
-// The same keys and values, 64 users x up to 64 iterations per workgroup, with the users' RATING ROWS read once instead of one
-// random access per sample: schedule_keys_kernel pulls two cache lines (indices, data) out of memory for every (user, iteration)
-// -- 2.0 GB per batch of 64 iterations on the ML-20M shape, a seventh of what the 64 iterations themselves move, and the
-// iterations running beside it pay for that share of the memory system (tools/schedule_interference.py).  Here a wavefront
+// Keys and values of a window, 64 users x up to 64 iterations per workgroup, with the users' RATING ROWS read once instead of one
+// random access per sample (two cache lines -- indices, data -- for every (user, iteration): 2.0 GB per batch of 64 iterations on
+// the ML-20M shape, which the iterations running beside it paid for: tools/schedule_interference.py).  Here a wavefront
 // takes 16 users one after the other: lane b draws iteration b's sample, the row comes in with coalesced loads (256 ratings
 // per round: most users' whole row), the lanes pick their ratings out of the registers (ds_bpermute); rows of more than
 // kRowRounds rounds fall back to two gathers per sample.  The tile leaves through LDS, so that every store is a run of 64
@@ -127,7 +96,7 @@ __global__ __launch_bounds__(256) void schedule_keys_tile_kernel(const int *__re
                                                                  const float *__restrict__ data, const int *__restrict__ item_rank,
                                                                  int n_rows, int n_batch, int item_bits, uint32_t sentinel, uint64_t seed,
                                                                  uint64_t iter0, int user_offset, uint32_t *__restrict__ keys,
-                                                                 uint64_t *__restrict__ vals, int batch_keys) {
+                                                                 uint64_t *__restrict__ vals) {
     __shared__ uint32_t t_key[64 * kTileStride];
     __shared__ uint32_t t_rat[64 * kTileStride];  // the rating's bits; the user (the value's upper half) is known at the store
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -195,7 +164,7 @@ __global__ __launch_bounds__(256) void schedule_keys_tile_kernel(const int *__re
         for (int j = 0; j < 4; ++j) rank[j] = item_rank[y[j]];  // (item 0 for users without ratings: unused)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t key = live[j] ? (batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u) | static_cast<uint32_t>(rank[j]) : sentinel;
+            const uint32_t key = live[j] ? static_cast<uint32_t>(rank[j]) : sentinel;
             t_key[b * kTileStride + 16 * wave + u0 + j] = key;
             t_rat[b * kTileStride + 16 * wave + u0 + j] = live[j] ? r[j] : 0u;
         }
@@ -216,13 +185,12 @@ __global__ __launch_bounds__(256) void schedule_keys_tile_kernel(const int *__re
 // position of iteration b whose popularity rank is >= r (r = 0 .. n_ranks).  Runs behind the sort on the schedule stream, so
 // that a two-wave block finds its chains with two loads instead of two binary searches of ~17 dependent loads each at the
 // head of every iteration (6-10 us of its ~50: the searches were the first thing the iteration's longest chains did).
-__global__ __launch_bounds__(kBlock) void chain_ranges_kernel(const uint32_t *__restrict__ keys, int n_active, int n_ranks, int item_bits,
-                                                              int *__restrict__ ranges, size_t stride, int batch_keys) {
+__global__ __launch_bounds__(kBlock) void chain_ranges_kernel(const uint32_t *__restrict__ keys, int n_active, int n_ranks,
+                                                              int *__restrict__ ranges, size_t stride) {
     const int b = blockIdx.x;
     const uint32_t *kb = keys + static_cast<size_t>(b) * stride;
-    const uint32_t key_base = batch_keys ? static_cast<uint32_t>(b) << item_bits : 0u;
     for (int r = threadIdx.x; r <= n_ranks; r += kBlock)
-        ranges[static_cast<size_t>(b) * (n_ranks + 1) + r] = lower_bound_key(kb, n_active, key_base + static_cast<uint32_t>(r));
+        ranges[static_cast<size_t>(b) * (n_ranks + 1) + r] = lower_bound_key(kb, n_active, static_cast<uint32_t>(r));
 }
 
 // ---- one update inside a chain: the user's row comes in, the item row / bias stay in registers -------------
@@ -445,7 +413,7 @@ __device__ __forceinline__ void duo_compute(DuoLds<W, S> &l, int buf, int n_vali
 // tile's memory traffic, wave 3 only keeps the barriers company.
 template <int W, int S>
 __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32_t *__restrict__ keys,
-                                                  const uint64_t *__restrict__ vals, int n_active, uint32_t key_base,
+                                                  const uint64_t *__restrict__ vals, int n_active,
                                                   int n_hot, const int *__restrict__ item_of_rank, int rank_lo,
                                                   const int *__restrict__ ranges) {
     constexpr int kChains = DuoShape<W, S>::kChains, kTile = DuoShape<W, S>::kTile;
@@ -465,8 +433,8 @@ __device__ __forceinline__ void run_hot_block_duo(const SgdArgs &a, const uint32
                 begin = ranges[r];
                 end = ranges[r + 1];
             } else {
-                begin = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r));
-                end = lower_bound_key(keys, n_active, key_base | static_cast<uint32_t>(r + 1));
+                begin = lower_bound_key(keys, n_active, static_cast<uint32_t>(r));
+                end = lower_bound_key(keys, n_active, static_cast<uint32_t>(r + 1));
             }
         }
         if (lane == 0) {
@@ -636,167 +604,45 @@ template <int J>
 __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const uint32_t *__restrict__ keys,
                                                              const uint64_t *__restrict__ vals, int n_active,
                                                              const int *__restrict__ item_of_rank,
-                                                             uint32_t item_mask, uint32_t key_base, int n_hot,
+                                                             uint32_t item_mask, int n_hot,
                                                              int hot_blocks, int rank_lo, const int *__restrict__ ranges) {
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
         // two-wave form for every row width: 32 lanes x 1 slot when 65 <= ld <= 128, else 16 lanes x J slots
-        run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, key_base, n_hot, item_of_rank, rank_lo,
-                                                                         ranges);
+        run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, n_hot, item_of_rank, rank_lo, ranges);
         return;
     }
     walk_group<J>(a, keys, vals, n_active, item_of_rank, item_mask, n_hot,
                   static_cast<int>((blockIdx.x - hot_blocks) * kBlock + threadIdx.x) / kGroup);
 }
 
-// The walk alone (block-solve mode runs it beside the two-wave chains on a stream of its own: inside sgd_ordered_kernel
-// every block reserves the two-wave role's 33 KB of LDS, which halves the walk's occupancy).
-template <int J>
-__global__ __launch_bounds__(kBlock) void sgd_walk_kernel(SgdArgs a, const uint32_t *__restrict__ keys,
-                                                          const uint64_t *__restrict__ vals, int n_active,
-                                                          const int *__restrict__ item_of_rank, uint32_t item_mask, int n_hot) {
-    walk_group<J>(a, keys, vals, n_active, item_of_rank, item_mask, n_hot, static_cast<int>(blockIdx.x * kBlock + threadIdx.x) / kGroup);
-}
-
-// Small sets: ALL iterations of a schedule batch in ONE launch.  When a whole iteration's grid is co-resident (ML-1M shape: 378
-// walk blocks + the two-wave blocks on 256 CUs) the kernel boundary between two iterations -- what carries the user rows from the
-// workgroup that wrote them to the one that reads them next -- becomes the grid barrier of the resident Hogwild launches
-// (grid_barrier.hpp: XCD-hierarchical, release = one L2 write-back per XCD, acquire = L1 invalidate, bounded spins) -- the form
-// VERDICT r3 asked for against training.cu:107-115's cadence of one launch per iteration.  Same schedule, same roles, same
-// arithmetic: bit-identical to the launch-per-iteration form.  Measured on the ML-1M shape (f = 50): 18.1 us per iteration
-// against 15.6 with a launch per iteration -- the barrier costs more than the boundary -- so it is opt-in, not the default.
-template <int J>
-__global__ __launch_bounds__(kBlock) void sgd_ordered_persistent_kernel(SgdArgs a, const uint32_t *__restrict__ keys,
-                                                                        const uint64_t *__restrict__ vals, size_t stride, int n_active,
-                                                                        const int *__restrict__ item_of_rank, uint32_t item_mask,
-                                                                        int n_hot, int hot_blocks, int rank_lo,
-                                                                        const int *__restrict__ ranges, int ranges_stride, int n_iters,
-                                                                        gridbar::Args ra) {
-    __shared__ gridbar::BarrierShared s_barrier;
-    if (threadIdx.x == 0) gridbar::barrier_census(ra, &s_barrier);
-    __syncthreads();
-    if (!s_barrier.ok) return;  // the grid is not co-resident: nothing is run, the host reports it
-    for (int b = 0; b < n_iters; ++b) {
-        const uint32_t *kb = keys + static_cast<size_t>(b) * stride;
-        const uint64_t *vb = vals + static_cast<size_t>(b) * stride;
-        const int *rb = ranges ? ranges + static_cast<size_t>(b) * ranges_stride : nullptr;
-        if (static_cast<int>(blockIdx.x) < hot_blocks)
-            run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, kb, vb, n_active, 0u, n_hot, item_of_rank, rank_lo, rb);
-        else
-            walk_group<J>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot,
-                          static_cast<int>((blockIdx.x - hot_blocks) * kBlock + threadIdx.x) / kGroup);
-        if (b + 1 == n_iters) break;  // the launch's end is the last boundary
-        gridbar::barrier_arrive(ra, static_cast<unsigned>(b + 1), &s_barrier);
-        if (!gridbar::barrier_wait(ra, static_cast<unsigned>(b + 1), &s_barrier)) break;
-    }
-}
-
-std::atomic<int> g_persistent_launches{0};
-
-// true: the batch's iterations were queued as ONE persistent launch; false: not eligible / refused -- launch per iteration
-template <int J>
-bool launch_persistent(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, size_t stride, int n_active, const int *item_of_rank,
-                       uint32_t item_mask, int n_hot, int rank_lo, const int *ranges, int ranges_stride, int n_iters, hipStream_t stream) {
-    const int chains_per_block = DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains;
-    int hot_blocks = (std::max(n_hot - rank_lo, 0) + chains_per_block - 1) / chains_per_block;
-    const int walk_blocks = (n_active + kGroupsPerBlock - 1) / kGroupsPerBlock;
-    int blocks = hot_blocks + walk_blocks;
-    static std::mutex mutex;
-    static std::map<int, int> per_cu_by_device;  // co-resident workgroups per CU of this instantiation (occupancy query, once)
-    int dev = 0;
-    CU2REC_HIP(hipGetDevice(&dev));
-    int per_cu = 0;
-    {
-        std::lock_guard<std::mutex> lock(mutex);
-        auto it = per_cu_by_device.find(dev);
-        if (it == per_cu_by_device.end()) {
-            int q = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, sgd_ordered_persistent_kernel<J>, kBlock, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                q = 0;
-            }
-            it = per_cu_by_device.emplace(dev, q).first;
-        }
-        per_cu = it->second;
-    }
-    if (per_cu < 1) return false;
-    GridBarrierBlock bar = grid_barrier_begin(stream);
-    // every block of the grid must hold a CU slot for the whole launch; leave one slot per CU to whatever else runs (the
-    // schedule kernels of the next batch), or the grid could wait at its first barrier for workgroups that cannot start
-    const long long capacity = static_cast<long long>(bar.cus) * std::max(per_cu - 1, 1);
-    if (blocks > capacity || !bar.cooperative) {
-        grid_barrier_end(stream);
-        return false;
-    }
-    SgdArgs args = a;
-    gridbar::Args ra{bar.words, bar.status, 0};
-    uint32_t key_base = 0u;
-    (void)key_base;
-    void *params[] = {&args,   &keys,       &vals,   &stride,        &n_active, &item_of_rank, &item_mask, &n_hot,
-                      &hot_blocks, &rank_lo, &ranges, &ranges_stride, &n_iters,  &ra};
-    const hipError_t launched = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(sgd_ordered_persistent_kernel<J>), dim3(blocks),
-                                                           dim3(kBlock), params, 0, stream);
-    grid_barrier_end(stream);
-    if (launched == hipErrorCooperativeLaunchTooLarge || launched == hipErrorLaunchOutOfResources) {
-        (void)hipGetLastError();  // a refusal, not an error: one launch per iteration instead
-        std::lock_guard<std::mutex> lock(mutex);
-        per_cu_by_device[dev] = 0;  // ... and do not ask again on this device
-        return false;
-    }
-    CU2REC_HIP(launched);
-    g_persistent_launches.fetch_add(1);
-    return true;
-}
-
-bool launch_chains_persistent(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, size_t stride, int n_active,
-                              const int *item_of_rank, uint32_t item_mask, int n_hot, int rank_lo, const int *ranges, int ranges_stride,
-                              int n_iters, hipStream_t stream) {
-    switch (slots_per_lane(a.nslots)) {
-        case 1: return launch_persistent<1>(a, keys, vals, stride, n_active, item_of_rank, item_mask, n_hot, rank_lo, ranges, ranges_stride, n_iters, stream);
-        case 2: return launch_persistent<2>(a, keys, vals, stride, n_active, item_of_rank, item_mask, n_hot, rank_lo, ranges, ranges_stride, n_iters, stream);
-        case 3: return launch_persistent<3>(a, keys, vals, stride, n_active, item_of_rank, item_mask, n_hot, rank_lo, ranges, ranges_stride, n_iters, stream);
-        case 4: return launch_persistent<4>(a, keys, vals, stride, n_active, item_of_rank, item_mask, n_hot, rank_lo, ranges, ranges_stride, n_iters, stream);
-        default: return false;  // (wider rows: small sets of such rows keep the launch per iteration)
-    }
-}
-
-// roles: kRoleDuo = the two-wave chains of ranks [rank_lo, n_hot), kRoleWalk = the walk of ranks >= n_hot; both in one launch
-// (the ordered mode), or one launch each (block-solve mode, two streams)
-constexpr int kRoleDuo = 1, kRoleWalk = 2;
-
+// One iteration's chains of ranks >= rank_lo: the two-wave chains of ranks [rank_lo, n_hot) and the walk of the rest, one launch.
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
-                  uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles, const int *ranges,
-                  hipEvent_t stop) {
+                  uint32_t item_mask, int n_hot, hipStream_t stream, int rank_lo, const int *ranges, hipEvent_t stop) {
     const int chains_per_block = DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains;
     const int hot_blocks = (std::max(n_hot - rank_lo, 0) + chains_per_block - 1) / chains_per_block;
     const int walk_blocks = (n_active + kGroupsPerBlock - 1) / kGroupsPerBlock;
-    if (roles == kRoleWalk) {
-        hipLaunchKernelGGL(sgd_walk_kernel<J>, dim3(walk_blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active, item_of_rank,
-                           item_mask, n_hot);
-        return;
-    }
-    const int blocks = hot_blocks + ((roles & kRoleWalk) ? walk_blocks : 0);
+    const int blocks = hot_blocks + walk_blocks;
     if (blocks == 0) return;
     if (stop)  // the event rides on the kernel's completion signal (see bs_launch_gram)
         hipExtLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, stop, 0, a, keys, vals, n_active,
-                              item_of_rank, item_mask, key_base, n_hot, hot_blocks, rank_lo, ranges);
+                              item_of_rank, item_mask, n_hot, hot_blocks, rank_lo, ranges);
     else
         hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,
-                           item_of_rank, item_mask, key_base, n_hot, hot_blocks, rank_lo, ranges);
+                           item_of_rank, item_mask, n_hot, hot_blocks, rank_lo, ranges);
 }
 
 void launch_chains(const SgdArgs &a, const uint32_t *kb, const uint64_t *vb, int n_active, const int *item_of_rank,
-                   uint32_t item_mask, uint32_t key_base, int n_hot, hipStream_t stream, int rank_lo, int roles = kRoleDuo | kRoleWalk,
-                   const int *ranges = nullptr, hipEvent_t stop = nullptr) {
+                   uint32_t item_mask, int n_hot, hipStream_t stream, int rank_lo, const int *ranges = nullptr, hipEvent_t stop = nullptr) {
     switch (slots_per_lane(a.nslots)) {
-        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
-        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
-        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
-        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
-        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
-        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
-        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
-        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, key_base, n_hot, stream, rank_lo, roles, ranges, stop); break;
+        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
+        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
+        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
+        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
+        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
+        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
+        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
+        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
         default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
     }
 }
@@ -852,21 +698,16 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
             keys[slot][i].allocate(cap);
             vals[slot][i].allocate(cap);
         }
-    hipcub::DoubleBuffer<uint32_t> dk(keys[0][0].ptr, keys[0][1].ptr);
-    hipcub::DoubleBuffer<uint64_t> dv(vals[0][0].ptr, vals[0][1].ptr);
     temp_bytes = 0;
-    CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, dk, dv, static_cast<int>(cap), 0, 32, nullptr));
     {
-        // the segmented form (run()): every iteration of a batch is a segment of n_rows pairs
+        // every iteration of a batch is a segment of n_rows pairs of the sort
         std::vector<int> offs(static_cast<size_t>(max_batch) + 1);
         for (int b = 0; b <= max_batch; ++b) offs[b] = static_cast<int>(static_cast<size_t>(b) * n_rows);
         seg_offsets.allocate(offs.size());
         seg_offsets.upload(offs.data(), offs.size());
-        size_t seg_bytes = 0;
-        CU2REC_HIP(rocprim::segmented_radix_sort_pairs<SegSortConfig>(nullptr, seg_bytes, keys[0][0].ptr, keys[0][1].ptr, vals[0][0].ptr,
+        CU2REC_HIP(rocprim::segmented_radix_sort_pairs<SegSortConfig>(nullptr, temp_bytes, keys[0][0].ptr, keys[0][1].ptr, vals[0][0].ptr,
                                                                        vals[0][1].ptr, static_cast<unsigned>(cap), static_cast<unsigned>(max_batch),
                                                                        seg_offsets.ptr, seg_offsets.ptr + 1, 0u, 32u, nullptr));
-        temp_bytes = std::max(temp_bytes, seg_bytes);
     }
     temp.allocate(temp_bytes + 16);
     // block-solve workspace
@@ -911,7 +752,6 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         walk_begin[slot].allocate(max_batch);
         bs_chains[slot].allocate(static_cast<size_t>(max_batch) * std::max(n_hot_bs, 1));
         bs_blocks[slot].allocate(static_cast<size_t>(max_batch) * max_blocks);
-        bs_order[slot].allocate(static_cast<size_t>(max_batch) * std::max(max_blocks, 1));
     }
     {
         // The next batch's schedule is built beside the iterations that consume this batch's, on a stream of the lowest priority
@@ -929,12 +769,6 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     if (n_hot_bs > 0) {
         Mbuf.allocate(static_cast<size_t>(max_blocks) * kBsRecFloats);
         ebuf.allocate(static_cast<size_t>(max_blocks) * kBsLinks);
-        gram_flag.allocate(max_blocks);
-        gram_flag.zero();  // epochs start at 1
-        chain_prog.allocate(static_cast<size_t>(n_hot_bs) * kBsProgWords);
-        chain_prog.zero();
-        pipe_done.allocate(16);
-        pipe_done.zero();
         solve_started.allocate(16);
         solve_started.zero();
         gram_done.allocate(32 * 16);
@@ -954,25 +788,19 @@ OrderedSchedule::~OrderedSchedule() {
         if (ev_ready[slot]) (void)hipEventDestroy(ev_ready[slot]);
         if (ev_consumed[slot]) (void)hipEventDestroy(ev_consumed[slot]);
     }
-    if (solve) (void)hipStreamDestroy(solve);
     if (upd) (void)hipStreamDestroy(upd);
-    for (hipEvent_t e : {ev_call, ev_upd, ev_solve, ev_gram, ev_last})
+    for (hipEvent_t e : {ev_call, ev_upd, ev_gram, ev_last})
         if (e) (void)hipEventDestroy(e);
 }
 
-namespace {
-std::atomic<int> g_bs_affine_blocks{-1};  // -1: not yet initialised from the environment
-}
-
-int ordered_persistent_launches() { return g_persistent_launches.load(); }
-
-// How the block-solve mode forks and joins its side stream: 2 (default) gate kernel + device-side join, 1 gate kernel + event
-// join, 0 events both ways.  CU2REC_BS_GATE in the environment decides; without it, a process running under a COUNTER pass of
-// rocprofv3 (--pmc: the tool exports ROCPROF_COUNTER_COLLECTION) takes 0 -- a counter pass serialises kernels across streams, and
-// the device-side join would wait for a signal kernel the profiler does not let run before the waiting kernel has ended.
+// How the block-solve mode forks and joins its side stream: 2 (default) gate kernel + device-side join, 0 events both ways.
+// CU2REC_BS_GATE in the environment decides; without it, a process running under a COUNTER pass of rocprofv3 (--pmc: the tool exports
+// ROCPROF_COUNTER_COLLECTION) takes 0 -- a counter pass serialises kernels across streams, and the device-side join would wait for a
+// signal kernel the profiler does not let run before the waiting kernel has ended.  Same kernels, same bytes, same results
+// (tests/test_gpu_blocksolve.py runs both).
 int bs_gate_mode() {
     static const int mode = [] {
-        if (const char *env = std::getenv("CU2REC_BS_GATE")) return std::atoi(env);
+        if (const char *env = std::getenv("CU2REC_BS_GATE")) return std::atoi(env) != 0 ? 2 : 0;
         if (const char *pmc = std::getenv("ROCPROF_COUNTER_COLLECTION"))
             if (*pmc && std::string(pmc) != "0" && std::string(pmc) != "False" && std::string(pmc) != "false") return 0;
         return 2;
@@ -980,31 +808,8 @@ int bs_gate_mode() {
     return mode;
 }
 
-int blocksolve_affine_blocks(int blocks) {
-    int prev = g_bs_affine_blocks.load();
-    if (prev < 0) {
-        const char *env = std::getenv("CU2REC_BLOCKSOLVE_AFFINE");
-        const int init = env ? std::max(0, std::atoi(env)) : 0;
-        g_bs_affine_blocks.compare_exchange_strong(prev, init);
-        prev = g_bs_affine_blocks.load();
-    }
-    if (blocks >= 0) g_bs_affine_blocks.store(blocks);
-    return prev;
-}
-
 namespace {
 std::atomic<int> g_bs_lookahead{-1};  // -1: not yet initialised from the environment
-}
-
-// Workgroups of the pipelined phase 3 (bs_update_pipe_kernel): persistent, so few enough to leave the side kernel its room, and enough
-// to keep up with the chains (a block takes a workgroup a few microseconds; the chains together deliver a few dozen blocks per microsecond).
-int blocksolve_pipe_grid(int set) {
-    static int grid = [] {
-        const char *e = std::getenv("CU2REC_BLOCKSOLVE_PIPE_GRID");
-        return e && std::atoi(e) > 0 ? std::atoi(e) : 0;
-    }();
-    if (set > 0) grid = set;
-    return grid > 0 ? grid : 2 * bs_compute_units();
 }
 
 int blocksolve_lookahead_blocks(int blocks) {
@@ -1016,22 +821,6 @@ int blocksolve_lookahead_blocks(int blocks) {
         prev = g_bs_lookahead.load();
     }
     if (blocks >= 0) g_bs_lookahead.store(blocks);
-    return prev;
-}
-
-namespace {
-std::atomic<int> g_bs_affine_head{-1};  // -1: not yet initialised from the environment
-}
-
-int blocksolve_affine_head(int blocks) {
-    int prev = g_bs_affine_head.load();
-    if (prev < 0) {
-        const char *env = std::getenv("CU2REC_BLOCKSOLVE_AFFINE_HEAD");
-        const int init = env ? std::max(1, std::atoi(env)) : 9;
-        g_bs_affine_head.compare_exchange_strong(prev, init);
-        prev = g_bs_affine_head.load();
-    }
-    if (blocks >= 1) g_bs_affine_head.store(blocks);
     return prev;
 }
 
@@ -1088,105 +877,66 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             qstart.allocate(static_cast<size_t>(max_blocks) * a.ldq);
             qstart_ld = a.ldq;
         }
-        if (!solve) {
-            // default priorities all round: a high-priority queue whose workgroups cannot all be placed (more hot chains than
-            // CUs) held back the queues below it, including phase 1, which those workgroups wait for (a 300-chain test set
-            // ran into the waits' timeout)
-            CU2REC_HIP(hipStreamCreateWithFlags(&solve, hipStreamNonBlocking));
+        if (!upd) {
+            // default priority: a high-priority queue whose workgroups cannot all be placed (more hot chains than CUs) held back
+            // the queues below it (a 300-chain test set ran into the waits' timeout)
             CU2REC_HIP(hipStreamCreateWithFlags(&upd, hipStreamNonBlocking));
-            for (hipEvent_t *e : {&ev_call, &ev_upd, &ev_solve, &ev_gram}) CU2REC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            for (hipEvent_t *e : {&ev_call, &ev_upd, &ev_gram}) CU2REC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
     }
     const uint32_t item_mask = (1u << item_bits) - 1u;
     // ranks [0, n_hot) get a dedicated group each with deep prefetch; keep r + 1 representable in item_bits
-    int hot_wanted = kHotChains;
-    if (const char *env = std::getenv("CU2REC_ORDERED_HOT")) hot_wanted = std::max(0, std::atoi(env));  // tuning aid
-    const int n_hot = std::min(std::min(n_cols, hot_wanted), static_cast<int>(item_mask));
-    // Sample + sort (+ plan) of one batch into a slot, on the schedule stream: nothing in it depends on the model.
-
-    // SEGMENTED (default): the keys carry the rank only, and every iteration of the batch is sorted as a segment of its own
-    // (hipcub::DeviceSegmentedRadixSort: one workgroup per long segment; stable, so the order is the one the sort of the whole
-    // batch by (iteration, rank) gives).  The whole-batch sort is three chip-filling passes of 130 us each per 64 iterations,
-    // and the iterations that ran beside the schedule kernels took 175 instead of 92 us: a chain's workgroup needs most of a
-    // CU and is not placed while a sort pass keeps refilling every CU (8 us per iteration on average,
-    // tools/schedule_interference.py; stream priorities and more hardware queues change nothing; one slice of small sorts per
-    // iteration is host bound).  CU2REC_SCHED_SEGMENTED=0: the whole-batch sort.
-    static const bool segmented = !(std::getenv("CU2REC_SCHED_SEGMENTED") && std::atoi(std::getenv("CU2REC_SCHED_SEGMENTED")) == 0);
-    static const bool tile_keys = !(std::getenv("CU2REC_SCHED_KEYS_TILE") && std::atoi(std::getenv("CU2REC_SCHED_KEYS_TILE")) == 0);  // max_batch <= 64
-    const size_t seg = segmented ? static_cast<size_t>(n_rows) : static_cast<size_t>(n_active);  // an iteration's stride in the sorted arrays
+    const int n_hot = std::min(std::min(n_cols, kHotChains), static_cast<int>(item_mask));
+    // Sample + sort (+ plan) of one window into a slot, on the schedule stream: nothing in it depends on the model.  The keys carry
+    // the item's popularity rank only, and every iteration of the window is sorted as a segment of its own (stable, so users stay
+    // ascending inside a chain); iteration b of the window occupies [b * n_rows, b * n_rows + n_active) of the sorted arrays.
+    const size_t seg = static_cast<size_t>(n_rows);  // an iteration's stride in the sorted arrays
     auto schedule = [&](int slot, uint64_t first_iter, int nb) {
-        win[slot].valid = false;  // (until everything below has been queued: a launch that throws leaves no window behind)
-        if (segmented) {
-            const size_t n = static_cast<size_t>(nb) * n_rows;
-            const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 1 << 16));
-            if (slot_used[slot]) CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[slot], 0));  // its last batch has been run
-            if (tile_keys)
-                hipLaunchKernelGGL(schedule_keys_tile_kernel, dim3((n_rows + 63) / 64), dim3(256), 0, sched, a.indptr, a.indices, a.data,
-                                   item_rank.ptr, n_rows, nb, item_bits, 1u << item_bits, a.seed, first_iter, a.user_offset, keys[slot][0].ptr,
-                                   vals[slot][0].ptr, 0);
-            else
-                hipLaunchKernelGGL(schedule_keys_kernel, dim3(blocks), dim3(kBlock), 0, sched, a.indptr, a.indices, a.data, item_rank.ptr, n_rows, nb,
-                                   item_bits, 1u << item_bits, a.seed, first_iter, a.user_offset, keys[slot][0].ptr, vals[slot][0].ptr, 0);
-            CU2REC_HIP(hipGetLastError());
-            size_t bytes = temp_bytes;
-            CU2REC_HIP(rocprim::segmented_radix_sort_pairs<SegSortConfig>(temp.ptr, bytes, keys[slot][0].ptr, keys[slot][1].ptr, vals[slot][0].ptr,
-                                                                           vals[slot][1].ptr, static_cast<unsigned>(n), static_cast<unsigned>(nb),
-                                                                           seg_offsets.ptr, seg_offsets.ptr + 1, 0u,
-                                                                           static_cast<unsigned>(item_bits + 1), sched));
-            win[slot] = Window{true, a.seed, first_iter, nb, a.user_offset, a.indptr, blocksolve, keys[slot][1].ptr, vals[slot][1].ptr};
-            hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, win[slot].sk, n_active, n_range_ranks, item_bits,
-                               chain_ranges[slot].ptr, seg, 0);
-            CU2REC_HIP(hipGetLastError());
-            if (blocksolve)
-                bs_launch_plan(win[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
-                               bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, false, bs_order[slot].ptr);
-            CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
-            slot_used[slot] = true;
-            return;
-        }
-        const int b_bits = bits_for(nb);
-        const uint32_t sentinel = 1u << (item_bits + b_bits);
+        win[slot].valid = false;
+        // (the window is published only when everything below has been queued -- a launch that throws leaves none behind)
         const size_t n = static_cast<size_t>(nb) * n_rows;
-        const int blocks = static_cast<int>(std::min<size_t>((n + kBlock - 1) / kBlock, 1 << 16));
-        if (slot_used[slot]) CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[slot], 0));  // its last batch has been run
-        if (tile_keys)
-            hipLaunchKernelGGL(schedule_keys_tile_kernel, dim3((n_rows + 63) / 64), dim3(256), 0, sched, a.indptr, a.indices, a.data,
-                               item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, first_iter, a.user_offset, keys[slot][0].ptr,
-                               vals[slot][0].ptr, 1);
-        else
-            hipLaunchKernelGGL(schedule_keys_kernel, dim3(blocks), dim3(kBlock), 0, sched, a.indptr, a.indices, a.data,
-                               item_rank.ptr, n_rows, nb, item_bits, sentinel, a.seed, first_iter, a.user_offset,
-                               keys[slot][0].ptr, vals[slot][0].ptr, 1);
+        if (slot_used[slot]) CU2REC_HIP(hipStreamWaitEvent(sched, ev_consumed[slot], 0));  // its last window has been run
+        hipLaunchKernelGGL(schedule_keys_tile_kernel, dim3((n_rows + 63) / 64), dim3(256), 0, sched, a.indptr, a.indices, a.data,
+                           item_rank.ptr, n_rows, nb, item_bits, 1u << item_bits, a.seed, first_iter, a.user_offset, keys[slot][0].ptr,
+                           vals[slot][0].ptr);
         CU2REC_HIP(hipGetLastError());
-        hipcub::DoubleBuffer<uint32_t> dk(keys[slot][0].ptr, keys[slot][1].ptr);
-        hipcub::DoubleBuffer<uint64_t> dv(vals[slot][0].ptr, vals[slot][1].ptr);
         size_t bytes = temp_bytes;
-        CU2REC_HIP(hipcub::DeviceRadixSort::SortPairs(temp.ptr, bytes, dk, dv, static_cast<int>(n), 0,
-                                                      item_bits + b_bits + 1, sched));
-        win[slot] = Window{true, a.seed, first_iter, nb, a.user_offset, a.indptr, blocksolve, dk.Current(), dv.Current()};
-        hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, win[slot].sk, n_active, n_range_ranks, item_bits,
-                           chain_ranges[slot].ptr, seg, 1);
+        CU2REC_HIP(rocprim::segmented_radix_sort_pairs<SegSortConfig>(temp.ptr, bytes, keys[slot][0].ptr, keys[slot][1].ptr, vals[slot][0].ptr,
+                                                                       vals[slot][1].ptr, static_cast<unsigned>(n), static_cast<unsigned>(nb),
+                                                                       seg_offsets.ptr, seg_offsets.ptr + 1, 0u,
+                                                                       static_cast<unsigned>(item_bits + 1), sched));
+        Window w{true, a.seed, first_iter, nb, a.user_offset, a.indptr, blocksolve, keys[slot][1].ptr, vals[slot][1].ptr};
+        hipLaunchKernelGGL(chain_ranges_kernel, dim3(nb), dim3(kBlock), 0, sched, w.sk, n_active, n_range_ranks, chain_ranges[slot].ptr, seg);
         CU2REC_HIP(hipGetLastError());
         if (blocksolve)
-            bs_launch_plan(win[slot].sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
-                           bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg, true, bs_order[slot].ptr);
+            bs_launch_plan(w.sk, n_active, nb, n_hot_bs, item_bits, max_blocks, item_of_rank.ptr, chain_begin[slot].ptr,
+                           bs_chains[slot].ptr, bs_blocks[slot].ptr, walk_begin[slot].ptr, sched, seg);
         CU2REC_HIP(hipEventRecord(ev_ready[slot], sched));
         slot_used[slot] = true;
+        win[slot] = w;
     };
+    // (raw pointers: the arrays behind them are the caller's and may change between calls -- no window outlives the call, whether
+    // it returns or throws)
+    struct DropWindows {
+        OrderedSchedule *s;
+        ~DropWindows() {
+            if (!s->speculate) s->win[0].valid = s->win[1].valid = false;
+        }
+    } drop_windows{this};
     // A call usually continues where the last one stopped (cu2rec_train's segments, a bench's steps, a sharded run's periods): its
     // iterations are then already scheduled -- in the window the earlier calls have been running out of, or in the one that was
     // scheduled ahead beside them.  Otherwise (first call, another seed / offset / mode, a jump in the iteration number) a window
-    // for what this call needs is scheduled now, and the call's first iteration waits for it.
+    // for what this call needs is scheduled now, and the call's first iteration waits for it.  A window is keyed on (seed, user
+    // offset, indptr address, mode): with `speculate` (owned cu2rec_csr objects only) the CSR arrays are IMMUTABLE for the
+    // object's lifetime, which is what lets a window outlive the call that scheduled it.
     auto holds = [&](const Window &w, uint64_t it) {
         return w.valid && w.seed == a.seed && w.user_offset == a.user_offset && w.indptr == a.indptr && w.blocksolve == blocksolve &&
                it >= w.iter_begin && it < w.iter_begin + static_cast<uint64_t>(w.nb);
     };
-    if (blocksolve) {  // the other two streams of the mode start behind everything the caller has queued so far
+    if (blocksolve) {  // the side stream starts behind everything the caller has queued so far
         CU2REC_HIP(hipEventRecord(ev_call, stream));
-        CU2REC_HIP(hipStreamWaitEvent(solve, ev_call, 0));
         CU2REC_HIP(hipStreamWaitEvent(upd, ev_call, 0));
     }
-    bool upd_pending = false;  // phase 3 of an earlier iteration of THIS call has not been waited for by `stream` yet
     int done = 0;
     while (done < n_iters) {
         const uint64_t it_first = iter0 + static_cast<uint64_t>(done);
@@ -1204,9 +954,8 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         const int nb = std::min(n_iters - done, win[slot].nb - off);
         // The window BEHIND this one is scheduled beside this batch's iterations unless it exists already: as far as this call goes
         // on, or -- for the calls to come (`speculate`) -- a whole max_batch.  It is queued (on its own stream) BEHIND this batch's
-        // first iterations in host order: queueing it costs the host tens of microseconds (the segmented sort's launches), and at the
-        // start of a call the device is idle -- with the schedule queued first, the call's first phase 1 started ~100 us after the
-        // call did (kernel traces, round 4).
+        // first iterations in host order: queueing it costs the host tens of microseconds, and at the start of a call the device is
+        // idle -- with the schedule queued first, the call's first phase 1 started ~100 us after the call did (kernel traces, round 4).
         const uint64_t next_begin = win[slot].iter_begin + static_cast<uint64_t>(win[slot].nb);
         const long long call_beyond = static_cast<long long>(iter0 + static_cast<uint64_t>(n_iters)) - static_cast<long long>(next_begin);
         const int next_nb = speculate ? max_batch : static_cast<int>(std::min<long long>(max_batch, call_beyond));
@@ -1221,49 +970,30 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         const uint64_t *sv = win[slot].sv + static_cast<size_t>(off) * seg;
         a.iters = 1;
         if (blocksolve) {
-            // One iteration = four launches: phase 1 (bs_gram_kernel: every block's inverse factor), phase 2 (bs_solve_kernel: one
-            // workgroup per chain), phase 3 (bs_update_kernel: the user side), and the other items' chains (two-wave form / walk).
-            // The kernels hand blocks over through device words tagged with the iteration's epoch (blocksolve.hpp), so they are
-            // correct in EITHER launch topology:
-            //  * sequential (default): `stream`: phase 1 -> phase 2 -> phase 3; second stream: the other chains, forked behind
-            //    phase 1 and joined in front of the next phase 1.  Every producer has finished before its consumer starts: the
-            //    device-side waits fall through.
-            //  * concurrent (CU2REC_BS_CONCURRENT=1, opt-in): `stream`: phase 1 -> the other chains; `solve`: phase 2, which
-            //    starts on a block as soon as phase 1 has announced it; second stream: phase 3 behind phase 1, its workgroups
-            //    waiting chain by chain for phase 2's progress.  Measured at parity with the sequential topology (DESIGN.md
-            //    section 4: the chain stays the critical path) and it NEEDS the three streams to be three hardware queues -- the
-            //    HIP runtime multiplexes streams onto a small pool of queues, and two of these launches in one queue would wait
-            //    for each other until the bounded waits give up -- so it is not the default.
-            static const bool concurrent = std::getenv("CU2REC_BS_CONCURRENT") != nullptr && std::atoi(std::getenv("CU2REC_BS_CONCURRENT")) != 0;
-            CU2REC_HIP(hipStreamWaitEvent(solve, ev_ready[slot], 0));  // (concurrent: phase 2; pipelined: phase 3)
-            CU2REC_HIP(hipStreamWaitEvent(upd, ev_ready[slot], 0));
-            bool pipe_used = false;
+            // One iteration = four launches: `stream`: phase 1 (bs_gram_kernel: every block's inverse factor) -> phase 2
+            // (bs_solve_kernel: one workgroup per chain) -> phase 3 (bs_update_kernel: the user side); side stream `upd`: the other
+            // items' chains (two-wave form / walk), forked behind phase 1 -- beside it their thousands of workgroups take the CUs
+            // from phase 1's (measured: 71 instead of 19 us) -- and joined in front of the next phase 1, which reads rows they write.
+            //  * default (bs_gate_mode() == 2), no event on the main stream: phase 1's workgroups count themselves through, phase 2's
+            //    count themselves in, ONE wavefront queued in front of the side kernel (bs_gate_kernel) ends when both counts have
+            //    reached what the host has launched so far; a signal kernel behind the side kernel stores the iteration's number and
+            //    one extra workgroup of phase 3's launch waits for it.  Host order gram, solve, gate, side, signal, update: every
+            //    launch behind what it waits for (streams sharing a hardware queue serialise, they cannot wait for each other).
+            //  * events (mode 0; what a rocprofv3 counter pass gets): fork on phase 1's completion signal, join by an event wait in
+            //    front of the next phase 1 (5.4 + 2.5-3.3 us per iteration on the main stream: DESIGN.md section 4).
             const double la = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.q_reg));
             const double lc = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.ib_reg));
             unsigned *status = bs_status_word();
-            // chains of at least this many blocks take the affine form (sequential topology, n_factors <= 124)
-            // ... with their first aff_head blocks in the plain form (what the maps of the others take to build) in one workgroup and
-            // the rest in another (at most aff_tails chains), and only as many blocks as the launch of phase 2 can hold a workgroup
-            // for beside those: every workgroup of that launch must find a CU without another one of them leaving (the chains'
-            // second workgroups wait for the builders and for the first ones)
-            const int aff_head = blocksolve_affine_head(0);
-            const int aff_want = blocksolve_affine_blocks(-1);
-            const int aff_tails = std::min(n_hot_bs, 16);
-            const int aff_cap = std::min(std::max(bs_compute_units() - n_hot_bs - aff_tails, 0), max_blocks);
-            const int aff_min = (!concurrent && aff_want > 0 && bs_affine_supported(a.nslots) && aff_cap > aff_head + 1) ? std::max(aff_want, aff_head + 2) : 0;
-            if (aff_min > 0 && aff_nslots != a.nslots) {
-                CU2REC_HIP(hipStreamSynchronize(stream));
-                Tbuf.allocate(static_cast<size_t>(max_blocks) * bs_affine_t_floats(a.nslots));
-                Wbuf.allocate(static_cast<size_t>(max_blocks) * bs_affine_w_floats(a.nslots));
-                bstart.allocate(max_blocks);
-                hstate.allocate(static_cast<size_t>(std::max(n_hot_bs, 1)) * 128);
-                hstate.zero();  // epochs start at 1
-                aff_nslots = a.nslots;
-            }
+            const bool device_join = bs_gate_mode() != 0 && max_blocks > 0;
+            bool upd_pending = false;  // (event join) the side kernel of an earlier iteration of this batch has not been waited for yet
+#ifdef CU2REC_TEST_HOOKS  // fault-path tests only (build/test/libcu2rec_amd_hooks.so): 16 the signal is never sent, 32 the gate can never open
+            static const int dbg = std::getenv("CU2REC_BS_DBG") ? std::atoi(std::getenv("CU2REC_BS_DBG")) : 0;
+#else
+            constexpr int dbg = 0;
+#endif
             for (int b = 0; b < nb; ++b) {
                 if (b == std::min(2, nb - 1) && b > 0) schedule_next();  // (two iterations are queued: the device has work)
                 a.iter0 = iter0 + done + b;
-                if (++bs_epoch == 0) ++bs_epoch;
                 BsIteration it{};
                 it.keys = sk + static_cast<size_t>(b) * seg;
                 it.vals = sv + static_cast<size_t>(b) * seg;
@@ -1272,10 +1002,6 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.item_mask = item_mask;
                 it.chains = bs_chains[slot].ptr + static_cast<size_t>(off + b) * std::max(n_hot_bs, 1);
                 it.blocks = bs_blocks[slot].ptr + static_cast<size_t>(off + b) * max_blocks;
-                it.order = bs_order[slot].ptr + static_cast<size_t>(off + b) * max_blocks;
-                it.pipe = 0;
-                it.pipe_done = pipe_done.ptr;
-                it.pipe_target = 0;
                 it.walk_begin = walk_begin[slot].ptr + off + b;
                 it.item_of_rank = item_of_rank.ptr;
                 it.tables = tables.ptr;
@@ -1285,168 +1011,56 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.ebuf = ebuf.ptr;
                 it.qstart = qstart.ptr;
                 it.max_blocks = max_blocks;
-                // (sequential topology, rows the rings have LDS for; the affine form and the look-ahead form exclude each other)
-                const bool la_on = !concurrent && aff_min == 0 && la_ranks > 0 && bs_lookahead_supported(a.nslots);
+                const bool la_on = la_ranks > 0 && bs_lookahead_supported(a.nslots);  // (rows the rings have LDS for)
                 it.la_ranks = la_on ? la_ranks : 0;
                 it.la_cap = la_cap;
                 it.la_grid = la_on ? la_cap : 0;
                 it.Nbuf = Nbuf.ptr;
-                it.aff_min_blocks = aff_min;
-                it.aff_head = aff_head;
-                it.aff_cap = aff_cap;
-                it.aff_flag = gram_flag.ptr;
-                it.aff_tails = aff_tails;
-                it.hstate = hstate.ptr;
-                it.Tbuf = Tbuf.ptr;
-                it.Wbuf = Wbuf.ptr;
-                it.bstart = bstart.ptr;
-                it.concurrent = concurrent ? 1 : 0;
-                it.epoch = bs_epoch;
-                it.gram_flag = gram_flag.ptr;
-                it.chain_prog = chain_prog.ptr;
                 it.status = status;
                 it.solve_started = solve_started.ptr;
-                it.gram_done = nullptr;
-                it.side_seq = nullptr;
-                it.side_target = 0;
                 it.wait_ticks = bs_wait_ticks();
                 bs_get_stamps(&it.stamps, &it.stamps_cap);
-                static const int dbg = std::getenv("CU2REC_BS_DBG") ? std::atoi(std::getenv("CU2REC_BS_DBG")) : 0;  // timing experiments
-                it.dbg = dbg;
-                if (!concurrent) {
-                    it.started_target = 0;  // phase 2 is queued behind phase 1: nothing to wait for
-                    static const int gate_mode = bs_gate_mode();
-                    const bool device_join = gate_mode >= 2 && n_hot_bs > 0 && max_blocks > 0 && std::getenv("CU2REC_BS_MARKERS") == nullptr;
-                    if (upd_pending && !device_join) {  // join: the previous iteration's other chains may have written rows phase 1 reads
-                        CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));
-                    }  // (device_join: the previous iteration's phase 3 has waited for them, see below)
-                    // The other chains touch other items and other users than the hot ones: fork, run beside, join.  The fork
-                    // sits behind phase 1: workgroups of the side kernel that already fill the CUs would keep phase 1's waiting
-                    // (measured: 71 instead of 19 us).  Both events ride on their kernels' completion signals (CU2REC_BS_MARKERS=1:
-                    // separate hipEventRecord markers as in round 2, for comparison).
-                    static const bool markers = std::getenv("CU2REC_BS_MARKERS") != nullptr;
-                    static const bool gate = bs_gate_mode() != 0;  // CU2REC_BS_GATE=0: the event
-                    if (gate && !markers && n_hot_bs > 0 && max_blocks > 0) {  // (phase 1 is launched at all)
-                        // The fork without an event: phase 1's workgroups count themselves through, and ONE wavefront queued in front
-                        // of the side kernel (after phase 1 in host order: streams sharing a hardware queue serialise, they cannot
-                        // wait for each other) ends when the whole grid is through.  Phase 1 is a plain launch then: phase 2 starts
-                        // right behind it (an event riding on its completion signal costs 5 us before phase 2).
-                        // (the host's counts move only behind a launch that succeeded: a launch that throws leaves gate and counters
-                        // in step for the calls that follow)
-                        it.gram_done = gram_done.ptr;
-                        bs_launch_gram(a, it, stream);
-                        gram_done_target += static_cast<unsigned long long>(max_blocks + it.la_grid);
-                    } else {
-                        bs_launch_gram(a, it, stream, markers ? nullptr : ev_gram);
-                        if (markers) CU2REC_HIP(hipEventRecord(ev_gram, stream));
-                        CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
-                    }
-                    // Pipelined (CU2REC_BS_PIPE=1, opt-in): phase 3 runs BESIDE phase 2 as a grid of persistent workgroups on the third
-                    // stream, behind a gate of its own (phase 2's workgroups hold their CUs: a CU filled with waiting phase-3 workgroups
-                    // would have no room for a chain), taking each block as soon as its chain has announced it; what is left of phase 3
-                    // behind the longest chain is its last block, and the join -- with phase 3 AND the side kernel -- is one more
-                    // workgroup in phase 2's launch.  Measured SLOWER than phase 3 behind phase 2 (round 4, ML-20M shape: 88.5 against
-                    // 82.4 us per step): phase 3 moves 37 MB and the side kernel, which it then runs beside, is bound by the same memory
-                    // system (57.6 instead of 44.9 us) -- DESIGN.md section 4.
-                    static const bool pipe_ok = std::getenv("CU2REC_BS_PIPE") && std::atoi(std::getenv("CU2REC_BS_PIPE")) != 0;
-                    const bool pipe = pipe_ok && device_join && it.gram_done && aff_min == 0 && bs_pipe_supported(a.nslots);
-                    const int pipe_grid = std::min(max_blocks, blocksolve_pipe_grid(0));
-                    // The join: a signal kernel behind the side kernel, and one more workgroup in the main stream's last launch of the
-                    // iteration that waits for its word (the number is known before either is queued: the wait is on the device) -- the
-                    // next phase 1 follows that launch without an event.
-                    // (CU2REC_BS_DBG & 16, fault-path test: the signal is never sent -- the waiting workgroup gives up after
-                    // 15 x the bound, the status word is set and the next entry point returns CU2REC_EHIP)
-                    if (device_join) {
-                        it.side_seq = side_seq.ptr;
-                        it.side_target = side_seq_host + 1;
-                    }
-                    if (pipe) {
-                        it.pipe = 1;
-                        it.pipe_target = pipe_done_host + static_cast<unsigned long long>(pipe_grid);
-                    }
+                const int *ranges = chain_ranges[slot].ptr + static_cast<size_t>(off + b) * (n_range_ranks + 1);
+                if (device_join) {
+                    // (the host's counts move only behind a launch that succeeded: a launch that throws leaves gate and counters in
+                    // step for the calls that follow)
+                    it.gram_done = gram_done.ptr;
+                    it.side_seq = side_seq.ptr;
+                    it.side_target = side_seq_host + 1;
+                    bs_launch_gram(a, it, stream);
+                    gram_done_target += static_cast<unsigned long long>(max_blocks + it.la_grid);
                     bs_launch_solve(a, it, stream);
-                    if (it.gram_done) started_total += static_cast<unsigned long long>(n_hot_bs + (pipe ? 1 : 0));  // (counted by its workgroups only then)
-                    // (the gate behind phase 2 in host order: it also waits for phase 2's workgroups to hold their CUs)
-                    // (CU2REC_BS_DBG & 32, fault-path test: a gate that can never be satisfied -- it gives up after the bound and the run
-                    // goes on, results unchanged)
-                    if (it.gram_done)
-                        bs_launch_gate(gram_done.ptr, gram_done_target + ((dbg & 32) ? (1ull << 40) : 0ull), solve_started.ptr, started_total, upd);
-                    // (the side kernel's completion event is what the main stream waits for at the END of the batch; with the device-side
-                    // join only the batch's last side kernel carries it -- an event on a kernel's completion signal holds the next packet
-                    // of its queue back, here the signal kernel: 5.4 us per iteration in the kernel traces of round 4)
-                    const bool side_event = !markers && (!device_join || b == nb - 1);
-                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(off + b) << item_bits,
-                                  std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, kRoleDuo | kRoleWalk,
-                                  chain_ranges[slot].ptr + static_cast<size_t>(off + b) * (n_range_ranks + 1), side_event ? ev_upd : nullptr);
-                    if (markers) CU2REC_HIP(hipEventRecord(ev_upd, upd));
-                    if (device_join) {
-                        ++side_seq_host;
-                        if (!(dbg & 16)) bs_launch_signal(side_seq.ptr, side_seq_host, upd);
-                    }
-                    if (pipe) {
-                        bs_launch_gate(gram_done.ptr, gram_done_target, solve_started.ptr, started_total, solve);
-                        bs_launch_update_pipe(a, it, pipe_grid, solve);
-                        pipe_done_host += static_cast<unsigned long long>(pipe_grid);
-                        pipe_used = true;
-                    } else {
-                        bs_launch_update(a, it, stream);
-                    }
+                    started_total += static_cast<unsigned long long>(n_hot_bs);
+                    bs_launch_gate(gram_done.ptr, gram_done_target + ((dbg & 32) ? (1ull << 40) : 0ull), solve_started.ptr, started_total, upd);
+                    // (only the batch's last side kernel carries the event the main stream waits for at the END of the batch: an event
+                    // on a kernel's completion signal holds the next packet of its queue back, here the signal kernel: 5.4 us)
+                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, ranges,
+                                  b == nb - 1 ? ev_upd : nullptr);
+                    ++side_seq_host;
+                    if (!(dbg & 16)) bs_launch_signal(side_seq.ptr, side_seq_host, upd);
+                    bs_launch_update(a, it, stream);
+                } else {
+                    if (upd_pending) CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));  // join: rows the next phase 1 reads
+                    bs_launch_gram(a, it, stream, ev_gram);
+                    CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
+                    bs_launch_solve(a, it, stream);
+                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, ranges, ev_upd);
+                    bs_launch_update(a, it, stream);
                     upd_pending = true;
-                    continue;
                 }
-                // phase 2 first: its few workgroups take their CUs before anything else of this iteration asks for room
-                started_total += static_cast<unsigned long long>(bs_solve_grid(n_hot_bs));
-                it.started_target = started_total;
-                bs_launch_solve(a, it, solve);
-                // phase 1 reads user rows the previous iteration's phase 3 may have written
-                if (upd_pending) {
-                    CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));
-                }
-                bs_launch_gram(a, it, stream);
-                CU2REC_HIP(hipEventRecord(ev_gram, stream));
-                // The other chains (ranks [n_hot_bs, n_duo_bs): the ordered mode's two-wave form; beyond: its walk): other items,
-                // other users.  On the SAME stream, behind phase 1: beside it their thousands of workgroups take the CUs away from
-                // phase 1's (measured: 71 instead of 19 us), and a cross-stream edge costs 13-14 us each way on this runtime
-                // (phase 1 -> other chains -> next phase 1 on two streams: 106 us per iteration, 27 of them event latency).
-                launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, segmented ? 0u : static_cast<uint32_t>(off + b) << item_bits,
-                              std::max(n_duo_bs, n_hot_bs), stream, n_hot_bs, kRoleDuo | kRoleWalk,
-                              chain_ranges[slot].ptr + static_cast<size_t>(off + b) * (n_range_ranks + 1));
-                // phase 3 on a stream of its own, behind phase 1 (hence behind the previous iteration's other chains, whose rows
-                // it may rewrite, and behind the start of every phase-2 workgroup): its workgroups wait for the chains' progress
-                CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
-                bs_launch_update(a, it, upd);
-                CU2REC_HIP(hipEventRecord(ev_upd, upd));
-                upd_pending = true;
             }
             schedule_next();  // (a batch of one or two iterations)
             CU2REC_HIP(hipGetLastError());
-            // the batch's slot is free once all three streams are through with it
-            if (concurrent || pipe_used) {
-                CU2REC_HIP(hipEventRecord(ev_solve, solve));
-                CU2REC_HIP(hipStreamWaitEvent(stream, ev_solve, 0));
-            }
+            // the batch's slot is free once both streams are through with it
             CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));
-            upd_pending = false;  // (waited for)
             CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));
             done += nb;
             continue;
         }
-        // a small set: the batch's iterations in ONE persistent launch with a grid barrier where the kernel boundaries were
-        // (sgd_ordered_persistent_kernel).  OPT-IN (CU2REC_ORDERED_PERSISTENT=1): measured SLOWER than the launch per iteration on
-        // the ML-1M shape, 18.1 against 15.6 us per iteration (round 4) -- a grid barrier across eight XCDs (two atomic hops, an L2
-        // write-back per XCD, an L1 invalidate per CU) costs more than the kernel boundary it replaces
-        static const bool persistent_ok = std::getenv("CU2REC_ORDERED_PERSISTENT") && std::atoi(std::getenv("CU2REC_ORDERED_PERSISTENT")) != 0;
-        const bool persistent = persistent_ok && segmented && nb >= 2 &&
-                                launch_chains_persistent(a, sk, sv, seg, n_active, item_of_rank.ptr, item_mask, n_hot, 0,
-                                                         n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(off) * (n_range_ranks + 1) : nullptr,
-                                                         n_range_ranks + 1, nb, stream);
-        for (int b = 0; b < nb && !persistent; ++b) {
+        for (int b = 0; b < nb; ++b) {
             if (b == std::min(2, nb - 1) && b > 0) schedule_next();
             a.iter0 = iter0 + done + b;
-            const uint32_t *kb = sk + static_cast<size_t>(b) * seg;
-            const uint64_t *vb = sv + static_cast<size_t>(b) * seg;
-            const uint32_t key_base = segmented ? 0u : static_cast<uint32_t>(off + b) << item_bits;
-            launch_chains(a, kb, vb, n_active, item_of_rank.ptr, item_mask, key_base, n_hot, stream, 0, kRoleDuo | kRoleWalk,
+            launch_chains(a, sk + static_cast<size_t>(b) * seg, sv + static_cast<size_t>(b) * seg, n_active, item_of_rank.ptr, item_mask, n_hot, stream, 0,
                           n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(off + b) * (n_range_ranks + 1) : nullptr);
         }
         schedule_next();
@@ -1454,9 +1068,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
         CU2REC_HIP(hipEventRecord(ev_consumed[slot], stream));
         done += nb;
     }
-    // (raw pointers: the arrays behind them are the caller's and may change between calls -- no window outlives the call)
-    if (!speculate) win[0].valid = win[1].valid = false;
-    if (blocksolve) bs_report_status(stream);  // (every batch ended with `stream` behind the other two streams)
+    if (blocksolve) bs_report_status(stream);  // (every batch ended with `stream` behind the side stream)
     CU2REC_HIP(hipEventRecord(ev_last, stream));
     last_stream = stream;
     have_last = true;

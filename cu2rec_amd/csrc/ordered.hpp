@@ -34,7 +34,9 @@ struct OrderedSchedule {
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     bool slot_used[2] = {false, false};
     // Schedule the next call's first batch ahead (it reads the CSR arrays after run() has returned): only where the
-    // schedule lives and dies with the CSR it reads, i.e. the owned-object layer (cu2rec_csr); off for raw pointers.
+    // schedule lives and dies with the CSR it reads, i.e. the owned-object layer (cu2rec_csr), whose arrays are IMMUTABLE for the
+    // object's lifetime -- windows are keyed on (seed, user offset, indptr address, mode), not on the arrays' contents; off for raw
+    // pointers, whose windows never outlive the call.
     bool speculate = false;
     // A scheduled WINDOW of iterations per slot: [iter_begin, iter_begin + nb) of one (seed, user offset, CSR, mode).  A call runs the
     // iterations it asks for out of whichever window holds them, at whatever offset -- so calls shorter than a window (a bench's
@@ -69,25 +71,17 @@ struct OrderedSchedule {
     int n_range_ranks = 0;
     DeviceBuffer<BsChainDesc> bs_chains[2];
     DeviceBuffer<BsBlockDesc> bs_blocks[2];
-    DeviceBuffer<int> bs_order[2];  // the pipelined phase 3's block order, per iteration of the batch
     DeviceBuffer<float> tables, Mbuf, ebuf, qstart;
-    DeviceBuffer<float> Tbuf, Wbuf, bstart;  // affine form of the long chains' blocks (allocated on first use)
-    DeviceBuffer<unsigned long long> hstate;
-    int aff_nslots = 0;
-    // Block-solve mode: an iteration is four launches on three streams that run side by side -- `stream` (the caller's): phase 1,
-    // then the other items' chains (two-wave form + walk); `solve`: phase 2; `upd`: phase 3, behind phase 1 (ev_gram).  Phase 2
-    // waits for phase 1 block by block and phase 3 for phase 2 chain by chain through device words tagged with the iteration's
-    // epoch (blocksolve.hpp); one event edge per iteration crosses back: phase 3 of iteration i before phase 1 of i + 1 (ev_upd).
-    DeviceBuffer<unsigned> gram_flag;
-    DeviceBuffer<unsigned long long> chain_prog, solve_started, gram_done, pipe_done;
-    unsigned long long pipe_done_host = 0;  // phase-3 workgroups launched so far (pipelined topology)
+    // Block-solve mode: an iteration is four launches on two streams -- `stream` (the caller's): phases 1, 2, 3; `upd`: the other
+    // items' chains (two-wave form + walk) beside phases 2 and 3, forked behind phase 1 and joined in front of the next phase 1
+    // without events on the main stream (OrderedSchedule::run, blocksolve.hpp)
+    DeviceBuffer<unsigned long long> solve_started, gram_done;
     unsigned long long gram_done_target = 0;  // phase-1 workgroups launched so far (what gram_done will reach)
     DeviceBuffer<unsigned long long> side_seq;  // [1] number of the last iteration whose side kernel is complete (bs_launch_signal)
     unsigned long long side_seq_host = 0;
     unsigned long long started_total = 0;  // phase-2 workgroups launched so far (what solve_started will reach)
-    unsigned bs_epoch = 0;
-    hipStream_t solve = nullptr, upd = nullptr;
-    hipEvent_t ev_call = nullptr, ev_upd = nullptr, ev_solve = nullptr, ev_gram = nullptr;
+    hipStream_t upd = nullptr;
+    hipEvent_t ev_call = nullptr, ev_upd = nullptr, ev_gram = nullptr;
     // one stream at a time per schedule: a call on another stream than the last one first waits for that call's end
     hipEvent_t ev_last = nullptr;
     hipStream_t last_stream = nullptr;
@@ -103,15 +97,8 @@ float blocksolve_min_rate_base();   // the explicit value, or the default the au
 bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwise a schedule scales the default with its set
 
 int bs_gate_mode();  // fork / join of the block-solve mode's side stream (CU2REC_BS_GATE; 0 under a rocprofv3 counter pass)
-// persistent ordered launches queued so far in this process (CU2REC_ORDERED_PERSISTENT=1; tests check that the form really ran)
-int ordered_persistent_launches();
 // chains EXPECTED to be at least this many blocks of 64 links long run phase 2 in the look-ahead form (default 24: the top chains; 0: none;
 // schedules created later); blocks < 0 only queries
 int blocksolve_lookahead_blocks(int blocks);
-int blocksolve_pipe_grid(int set);  // workgroups of the pipelined phase 3 (0: query; default 2 per CU, env CU2REC_BLOCKSOLVE_PIPE_GRID)
-// chains of at least this many blocks of 64 links take the affine form (0: none); blocks < 0 only queries
-int blocksolve_affine_blocks(int blocks);
-// ... after their first `blocks` blocks in the plain form (>= 1; 0 only queries)
-int blocksolve_affine_head(int blocks);
 
 }  // namespace cu2rec

@@ -68,7 +68,6 @@ using namespace dev;
 
 constexpr int kResBlock = 512;                    // 8 wavefronts = 2 per SIMD: up to 256 VGPRs each
 constexpr int kResGroups = kResBlock / kGroup;    // 32 user groups per workgroup
-constexpr int kXcds = 8;                          // XCDs of an MI355X (single-XCD launches: cus / 8 workgroups run)
 
 using namespace gridbar;  // the barrier: grid_barrier.hpp
 
@@ -76,7 +75,6 @@ struct ResidentArgs {
     unsigned *words;       // the barrier block above (device memory)
     unsigned *status;      // set to 1 by a workgroup that gave up waiting (the host reads and clears it)
     float *sink;           // kSinkFloats floats nobody reads: where the updates of users without ratings are written
-    int local;             // 1: only the workgroups that share workgroup 0's XCD run (small sets: one L2, no write-back)
     int streamed;          // partial residency: users per group BEHIND the resident ones whose rows stay in memory (0: none)
 };
 constexpr int kSinkBias = 512;                 // sink[0 .. 511]: an item row, sink[512]: an item bias
@@ -164,20 +162,8 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
         for (int j = 0; j < J; ++j) my_lds[(rl * J + j) * kGroup] = row.v[j];
     };
     const int lane = threadIdx.x & (kGroup - 1);
-    int wg = blockIdx.x, n_wg = gridDim.x;
+    const int wg = blockIdx.x, n_wg = gridDim.x;
     bool alive = true;
-    if (ra.local) {  // the census comes first: it says who runs and as which workgroup
-        if (threadIdx.x == 0) barrier_census(ra, &s_barrier);
-        __syncthreads();
-        if (!s_barrier.part) return;
-        alive = s_barrier.ok != 0;
-        wg = s_barrier.index;
-        n_wg = s_barrier.n_mine;
-        if (static_cast<long long>(n_wg) * kResGroups * (R + (PART ? ra.streamed : 0)) < a.n_rows) {  // fewer workgroups on this XCD than the host counted on
-            if (threadIdx.x == 0) __hip_atomic_store(ra.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-    }
     const int group = wg * kResGroups + (threadIdx.x / kGroup);
     const int n_groups = n_wg * kResGroups;
 
@@ -243,7 +229,7 @@ __global__ __launch_bounds__(kResBlock) void sgd_resident_kernel(SgdArgs a, Resi
     float rating[M];
     draw(a.iter0, item, rating);
     const bool synced = !(CU2REC_RES_ABLATE & 1) && a.iters > 1;
-    if (synced && !ra.local) {
+    if (synced) {
         if (threadIdx.x == 0) barrier_census(ra, &s_barrier);
         __syncthreads();
         alive = s_barrier.ok != 0;  // false: the grid is not co-resident; nothing is run, the host reports it
@@ -497,7 +483,7 @@ DeviceState &state_for_current_device() {
         s.cus = prop.multiProcessorCount;
         int coop = 0;
         if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess) (void)hipGetLastError();
-        s.cooperative = coop != 0 && std::getenv("CU2REC_RESIDENT_PLAIN_LAUNCH") == nullptr;
+        s.cooperative = coop != 0;
         CU2REC_HIP(hipMalloc(reinterpret_cast<void **>(&s.words), (kBarrierWords + kLine) * sizeof(unsigned)));
         CU2REC_HIP(hipMemset(s.words, 0, (kBarrierWords + kLine) * sizeof(unsigned)));
         CU2REC_HIP(hipMalloc(reinterpret_cast<void **>(&s.sink), kSinkFloats * sizeof(float)));
@@ -523,36 +509,14 @@ int resident_policy(int set_to) {
         int from_env = kResidentAuto;
         if (const char *e = std::getenv("CU2REC_RESIDENT")) {
             const int v = std::atoi(e);
-            if (v >= kResidentOff && v <= kResidentLocal) from_env = v;
+            if (v >= kResidentOff && v <= kResidentForce) from_env = v;
         }
         int expected = -1;
         g_policy.compare_exchange_strong(expected, from_env);
     }
     const int prev = g_policy.load();
-    if (set_to >= kResidentOff && set_to <= kResidentLocal) g_policy.store(set_to);
+    if (set_to >= kResidentOff && set_to <= kResidentForce) g_policy.store(set_to);
     return prev;
-}
-
-GridBarrierBlock grid_barrier_begin(hipStream_t stream) {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    DeviceState &s = state_for_current_device();
-    if (s.have_last && s.last_stream != stream) CU2REC_HIP(hipStreamWaitEvent(stream, s.done, 0));  // never two at once
-    CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));               // counters start from zero
-    GridBarrierBlock b;
-    b.words = s.words;
-    b.status = s.words + kBarrierWords;
-    b.cooperative = s.cooperative;
-    b.cus = s.cus;
-    return b;
-}
-
-void grid_barrier_end(hipStream_t stream) {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    DeviceState &s = state_for_current_device();
-    CU2REC_HIP(hipMemcpyAsync(s.host_status, s.words + kBarrierWords, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
-    CU2REC_HIP(hipEventRecord(s.done, stream));
-    s.last_stream = stream;
-    s.have_last = true;
 }
 
 void resident_check_fault() {
@@ -623,25 +587,13 @@ namespace {
 
 // The launch geometry a call would get, or false if it would stream.  Caller holds g_mutex.
 bool plan_locked(int n_rows, int nslots, int n_iters, int update_items, DeviceState *&state, int &variant, int &blocks,
-                 int &users_per_group, bool &local, int &streamed) {
+                 int &users_per_group, int &streamed) {
     streamed = 0;
     const int policy = resident_policy(-1);
-    local = false;
     if (policy == kResidentOff || n_iters < 1 || n_rows < 1 || !update_items) return false;
     DeviceState &s = state_for_current_device();
     state = &s;
     int need = 0;
-    if (policy == kResidentLocal && s.cooperative && s.cus % kXcds == 0) {
-        // a set small enough for the CUs of ONE XCD: the whole grid is launched (one workgroup per CU, hence cus / 8 per
-        // XCD), the workgroups that share workgroup 0's XCD run
-        const long long groups = static_cast<long long>(s.cus / kXcds) * kResGroups;
-        const int need_local = static_cast<int>(std::min<long long>((n_rows + groups - 1) / groups, 1 << 20));
-        const int v = variant_for(slots_per_lane(nslots), need_local);
-        if (v >= 0 && s.usable[v]) {
-            variant = v, blocks = s.cus, users_per_group = kVariants[v].r, local = true;
-            return true;
-        }
-    }
     variant = geometry(n_rows, nslots, s.cus, need, blocks, streamed);
     if (variant < 0 || !s.usable[variant]) return false;  // the rows do not fit: stream them
     // Auto: the barrier costs a few microseconds where a kernel boundary costs one or two, so residency pays once
@@ -670,9 +622,7 @@ bool resident_plan(int n_rows, int n_factors, int n_iters, int *blocks_out, int 
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceState *s = nullptr;
     int variant = -1, blocks = 0, users_per_group = 0, streamed = 0;
-    bool local = false;
-    const bool yes = plan_locked(n_rows, (n_factors + 3) / 4, n_iters, 1, s, variant, blocks, users_per_group, local, streamed);
-    if (yes && local) blocks = s->cus / kXcds;  // the workgroups that run
+    const bool yes = plan_locked(n_rows, (n_factors + 3) / 4, n_iters, 1, s, variant, blocks, users_per_group, streamed);
     if (blocks_out) *blocks_out = yes ? blocks : 0;
     if (users_per_group_out) *users_per_group_out = yes ? users_per_group : 0;
     return yes;
@@ -682,14 +632,13 @@ bool resident_launch(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream)
     std::lock_guard<std::mutex> lock(g_mutex);
     DeviceState *sp = nullptr;
     int variant = -1, blocks = 0, users_per_group = 0, streamed = 0;
-    bool local = false;
-    if (!plan_locked(a.n_rows, a.nslots, n_iters, a.update_items, sp, variant, blocks, users_per_group, local, streamed)) return false;
+    if (!plan_locked(a.n_rows, a.nslots, n_iters, a.update_items, sp, variant, blocks, users_per_group, streamed)) return false;
     DeviceState &s = *sp;
 
     if (s.have_last && s.last_stream != stream) CU2REC_HIP(hipStreamWaitEvent(stream, s.done, 0));  // never two at once
     a.iter0 = iter0;
     a.iters = n_iters;
-    ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink, local ? 1 : 0, streamed};
+    ResidentArgs ra{s.words, s.words + kBarrierWords, s.sink, streamed};
     void *args[] = {&a, &ra};
     CU2REC_HIP(hipMemsetAsync(s.words, 0, kBarrierWords * sizeof(unsigned), stream));  // counters start from zero
     // A cooperative launch: the runtime checks the grid against what can be co-resident and REFUSES a larger one up

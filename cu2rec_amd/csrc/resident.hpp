@@ -10,10 +10,9 @@
 
 namespace cu2rec {
 
-// kResidentLocal: like Force, but a set that fits the CUs of ONE XCD runs there (one L2: a barrier without write-back)
-enum ResidentPolicy { kResidentOff = 0, kResidentAuto = 1, kResidentForce = 2, kResidentLocal = 3 };
+enum ResidentPolicy { kResidentOff = 0, kResidentAuto = 1, kResidentForce = 2 };
 
-// Process-wide policy: CU2REC_RESIDENT=0|1|2|3 in the environment at first use, or cu2rec_hogwild_resident().
+// Process-wide policy: CU2REC_RESIDENT=0|1|2 in the environment at first use, or cu2rec_hogwild_resident().
 int resident_policy(int set_to /* < 0: query only */);
 
 // Runs iterations [iter0, iter0 + n_iters) of `a` (pointers, hyper-parameters, seed, user_offset filled in) in
@@ -33,19 +32,6 @@ int resident_streamed_rows(int n_rows, int n_factors, int n_cus);
 
 // Launches the runtime refused on the current device because the grid could not be co-resident (those calls streamed).
 int resident_refusals();
-
-// The device's ONE grid-barrier block (grid_barrier.hpp), shared by every persistent launch of the library -- the resident Hogwild
-// launches here and the persistent ordered launches of ordered.hip: never two of them at once.  grid_barrier_begin waits (on
-// `stream`) for the previous user's end, zeroes the counters and hands out the block; grid_barrier_end queues the status word's
-// copy to the host behind the launch and marks the block's next user's start.  cooperative: may the launch be a cooperative one
-// (hipLaunchCooperativeKernel: the runtime refuses a grid that cannot be co-resident).
-struct GridBarrierBlock {
-    unsigned *words = nullptr, *status = nullptr;
-    bool cooperative = false;
-    int cus = 0;
-};
-GridBarrierBlock grid_barrier_begin(hipStream_t stream);
-void grid_barrier_end(hipStream_t stream);
 
 // Throws if an earlier resident launch on the current device gave up at a grid barrier (bounded spin).
 void resident_check_fault();

@@ -217,24 +217,14 @@ int cu2rec_sgd_update_ex(const int *indptr, const int *indices, const float *dat
                          int n_factors, const cu2rec_hyper *hyper, uint64_t seed, uint64_t iter0, int n_iters,
                          int mode, int update_items, int user_offset, const void *sample_pairs, void *stream);
 
-/* Hogwild launch blocking (process-wide, default 1 = the reference's cadence: one launch per iteration, every user's
- * update of iteration i visible before iteration i+1 starts, training.cu:107-113).  With k > 1 a launch performs k
- * consecutive updates per user with the user's row held in registers (P traffic / k); users are then up to k-1
- * iterations apart inside a launch -- still Hogwild, but not the reference's interleaving, so it is opt-in.
- * Returns the previous value; k < 1 only queries. */
-int cu2rec_hogwild_iters_per_launch(int k);
-
 /* Resident Hogwild launches (process-wide; replaces the launch loop of training.cu:107-113 with ONE persistent
  * launch per cu2rec_sgd_update call).  The iterations of a call keep the reference's cadence -- every user's update
  * of iteration i is visible to iteration i+1 -- but the boundary between them is a grid-wide barrier instead of a
  * kernel boundary, and every user's row stays in the register file for the whole call (no P traffic between
- * iterations).  Applies when all user rows of the CSR fit the register file + LDS (e.g. 204,000 users at f <= 128) and
- * hogwild_iters_per_launch is 1; otherwise the call runs one streaming launch per iteration as before.
- * policy: 0 never, 1 auto (default: when it fits and a call covers >= 4 iterations), 2 whenever it fits, 3 like 2 but a set
- * that fits the CUs of ONE XCD runs on those alone (the cooperative launch still covers the chip; the workgroups that share
- * workgroup 0's XCD run, their barrier needs no L2 write-back -- measured slower than streaming on MI355X, one L2 being an
- * eighth of the chip's bandwidth: profiles/r02_single_xcd_resident.log; kept for that measurement);
- * CU2REC_RESIDENT=0|1|2|3 in the environment sets the initial value.  Returns the previous policy; other values query.
+ * iterations).  Applies when all user rows of the CSR fit the register file + LDS (e.g. 204,000 users at f <= 128);
+ * otherwise the call runs one streaming launch per iteration as before.
+ * policy: 0 never, 1 auto (default: when it fits and a call covers >= 4 iterations), 2 whenever it fits;
+ * CU2REC_RESIDENT=0|1|2 in the environment sets the initial value.  Returns the previous policy; other values query.
  * A resident launch assumes the GPU to itself (one workgroup per CU, all co-resident).  It is a cooperative launch: a
  * grid the runtime finds too large to be co-resident is refused up front and that call runs one streaming launch per
  * iteration instead (cu2rec_hogwild_resident_refusals counts them) -- nothing is lost.  What a launch-time check cannot
@@ -256,9 +246,10 @@ int cu2rec_hogwild_resident_plan(int n_rows, int n_factors, int n_iters, int *bl
  * *lds_rows live in LDS; all may be NULL), 0 if they do not.  Policy and call length are not considered. */
 int cu2rec_hogwild_resident_geometry(int n_rows, int n_factors, int n_cus, int *blocks, int *users_per_group,
                                      int *lds_rows);
-/* Partial residency (round 4; n_factors <= 128): a set too large for the chip still runs as ONE launch per call -- the first
- * users_per_group - s users of every group resident as above, the other s streamed through the same pipeline, row in, update,
- * row out (the reference's loop is sgd.cu:22-75 either way).  Returns s for the geometry above: 0 = fully resident, > 0 = that
+/* Partial residency (round 4; n_factors <= 256: every row width with a compiled partial form): a set too large for the chip still
+ * runs as ONE launch per call -- of the users_per_group users of every group (cu2rec_hogwild_resident_geometry's figure INCLUDES the
+ * streamed ones) the first users_per_group - s are resident as above, the other s streamed through the same pipeline, row in,
+ * update, row out (the reference's loop is sgd.cu:22-75 either way).  Returns s for the geometry above: 0 = fully resident, > 0 = that
  * many streamed rows per group, -1 = no compiled form holds the set (one launch per iteration).  CU2REC_RESIDENT_PARTIAL=0
  * switches the partial forms off. */
 int cu2rec_hogwild_resident_streamed_rows(int n_rows, int n_factors, int n_cus);
@@ -290,15 +281,6 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
  * rate > 0 sets an explicit threshold, rate < 0 returns to the automatic one, rate == 0 only queries.  Returns what was in
  * force before the call: the explicit threshold, or -1 for automatic (so passing a returned value back restores it). */
 float cu2rec_blocksolve_min_rate(float rate);
-/* Long chains in the affine form (block-solve mode, n_factors <= 124; wider rows keep the plain form).  A chain of at least
- * `blocks` blocks of 64 updates (one item, one iteration) runs its first cu2rec_blocksolve_affine_head() blocks as every other
- * chain does; meanwhile extra workgroups of the same launch build, for each of its other blocks, the matrix that maps the
- * item's row and bias at the start of the block to those at its end, and the chain runs through those at one matrix-vector
- * product per block.  Only as many blocks take part as the launch can hold a workgroup for (compute units minus hot chains).
- * Process-wide, read at every SGD call; 0 = off; CU2REC_BLOCKSOLVE_AFFINE / CU2REC_BLOCKSOLVE_AFFINE_HEAD in the environment
- * set the initial values.  Both return the previous value; blocks < 0 (head: 0) only queries. */
-int cu2rec_blocksolve_affine_blocks(int blocks);
-int cu2rec_blocksolve_affine_head(int blocks);
 /* The longest chains in the look-ahead form (block-solve mode, n_factors <= 116; round 4; default: items expected to collect 24 blocks
  * and more per iteration -- the two or three longest chains of the ML-20M shape: -2.7 % per iteration).  Items EXPECTED to collect at
  * least `blocks` x 64 updates per iteration (the leading popularity ranks): phase 1 also builds, for every block of their chains
@@ -309,14 +291,9 @@ int cu2rec_blocksolve_affine_head(int blocks);
  * up to float rounding.  Process-wide, read when a schedule is created (like cu2rec_blocksolve_min_rate); 0 = off;
  * CU2REC_BLOCKSOLVE_LOOKAHEAD in the environment sets the initial value.  Returns the previous value; blocks < 0 only queries. */
 int cu2rec_blocksolve_lookahead_blocks(int blocks);
-/* Ordered mode on SMALL sets, opt-in (CU2REC_ORDERED_PERSISTENT=1 in the environment): all iterations of a schedule batch in ONE
- * persistent launch, a grid barrier where training.cu:107-115 has its kernel boundaries (only when a whole iteration's grid is
- * co-resident; bit-identical results).  Measured slower than the launch per iteration on the ML-1M shape (18.1 against 15.6 us),
- * hence not the default.  Returns how many such launches this process has queued so far. */
-int cu2rec_ordered_persistent_launches(void);
 /* Development aid: while `buffer` (device memory, 8 * (1 + 8 * capacity) bytes, zeroed by the caller) is set, every
  * wavefront of the block-solve kernels writes {kernel, id, start, end, 4 marks (trace builds)} in ticks of the 100 MHz device clock into record
- * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 5 walk, 6 affine builder, 7 cross blocks; records never written stay
+ * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 7 cross blocks; records never written stay
  * zero).  NULL switches it off. */
 int cu2rec_debug_blocksolve_stamps(void *buffer, int capacity);
 

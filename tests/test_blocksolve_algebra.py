@@ -105,91 +105,6 @@ def test_blocked_chain_f32_rounding_gap_is_small():
             assert np.abs(np.asarray(g, np.float64) - np.asarray(w, np.float64)).max() < 2e-5
 
 
-def affine_chain(P, ub, r, q, b, gb, lr, regs, B, dtype):
-    """The affine form behind the long chains (bs_gram_kernel's second half and the affine branch of bs_solve_kernel).
-    With the state s = (q, b), the extended user rows pt_k = (p_k, 1) and Lambda = diag(a, ..., a, c):
-        e       = M (r' - G s0),              G_k = Lambda^k pt_k,        M = (I + lr L)^-1, r' = r - gb - ub
-        s_end   = Lambda^n s0 + lr H^T e,      H_j = Lambda^(n-1-j) pt_j
-                = Lambda^n s0 - lr T' (s0, -1), T' = H^T W, W = M [G | r']      -- one (f+1) x (f+2) matrix per block
-    T' and W depend on the block's user rows only: they are built for all blocks at once, the chain itself is one
-    mat-vec per block, and the errors follow from the block start states afterwards (e = -W (s0, -1))."""
-    p_reg, q_reg, ub_reg, ib_reg = (dtype(v) for v in regs)
-    lr = dtype(lr)
-    a, c = 1.0 - float(lr) * float(q_reg), 1.0 - float(lr) * float(ib_reg)
-    ap, au = dtype(1.0 - float(lr) * float(p_reg)), dtype(1.0 - float(lr) * float(ub_reg))
-    f = P.shape[1]
-    P0, ub0 = P.astype(dtype), ub.astype(dtype)
-    s = np.concatenate([q.astype(dtype), [dtype(b)]])
-    apow = (a ** np.arange(B + 1)).astype(dtype)
-    cpow = (c ** np.arange(B + 1)).astype(dtype)
-    adel = (1.0 - a ** np.arange(B + 1)).astype(dtype)
-    cdel = (1.0 - c ** np.arange(B + 1)).astype(dtype)
-    blocks = []
-    # pass 1 (parallel over blocks on the device): W and T' of every block
-    for m0 in range(0, len(r), B):
-        Pm, n = P0[m0:m0 + B], min(B, len(r) - m0)
-        G = (Pm @ Pm.T).astype(dtype)
-        k, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
-        low = j < k
-        d = np.where(low, k - 1 - j, 0)
-        N = np.where(low, lr * (cpow[d] + apow[d] * G), dtype(0)).astype(dtype)
-        M = np.linalg.inv((np.eye(n) + N).astype(np.float64)).astype(dtype)
-        base = (r[m0:m0 + n].astype(dtype) - dtype(gb)) - ub0[m0:m0 + n]
-        kk = np.arange(n)
-        Gx = np.concatenate([Pm * apow[kk][:, None], cpow[kk][:, None], base[:, None]], axis=1).astype(dtype)   # [G | r']
-        H = np.concatenate([Pm * apow[n - 1 - kk][:, None], cpow[n - 1 - kk][:, None]], axis=1).astype(dtype)
-        W = (M @ Gx).astype(dtype)
-        T = (H.T @ W).astype(dtype)
-        blocks.append((m0, n, W, T))
-    # pass 2 (the chain): one mat-vec per block
-    starts = []
-    for m0, n, W, T in blocks:
-        starts.append(s.copy())
-        st = np.concatenate([s, [dtype(-1)]])
-        dec = np.concatenate([np.full(f, adel[n], dtype), [cdel[n]]])
-        s = ((s - dec * s) - lr * (T @ st)).astype(dtype)
-    # pass 3 (parallel over blocks): errors from the start states, then the user side as in blocked_chain
-    P_new, ub_new = np.empty_like(P0), np.empty_like(ub0)
-    errs = np.zeros(len(r), dtype)
-    for (m0, n, W, T), s0 in zip(blocks, starts):
-        Pm = P0[m0:m0 + n]
-        e = (-(W @ np.concatenate([s0, [dtype(-1)]]))).astype(dtype)
-        k, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
-        low = j < k
-        d = np.where(low, k - 1 - j, 0)
-        Tq = np.where(low, lr * apow[d] * e[None, :], dtype(0)).astype(dtype)
-        q0 = s0[:f]
-        Qh = ((q0[None, :] - adel[:n, None] * q0[None, :]) + Tq @ Pm).astype(dtype)
-        P_new[m0:m0 + n] = ap * Pm + lr * e[:, None] * Qh
-        ub_new[m0:m0 + n] = au * ub0[m0:m0 + n] + lr * e
-        errs[m0:m0 + n] = e
-    return P_new, ub_new, s[:f], s[f], errs
-
-
-@pytest.mark.parametrize("n,f,B", [(1, 8, 64), (63, 10, 64), (200, 100, 64), (1979, 100, 64), (450, 126, 64)])
-def test_affine_chain_equals_sequential_f64(n, f, B):
-    rng = np.random.default_rng(n * 1000 + f + 1)
-    P, q = rng.normal(0, 0.3, (n, f)), rng.normal(0, 0.3, f)
-    ub, b, r = rng.normal(0, 0.3, n), 0.2, rng.integers(1, 11, n) / 2.0
-    regs = (0.02, 0.03, 0.04, 0.05)
-    want = sequential_chain(P, ub, r, q, b, 3.5, 0.01, regs, np.float64)
-    got = affine_chain(P, ub, r, q, b, 3.5, 0.01, regs, B, np.float64)
-    for g, w in zip(got, want):
-        assert np.allclose(g, w, rtol=0, atol=1e-11), np.abs(np.asarray(g) - np.asarray(w)).max()
-
-
-def test_affine_chain_f32_rounding_gap_is_small():
-    rng = np.random.default_rng(8)
-    n, f = 1979, 100
-    P, q = rng.normal(0, 0.3, (n, f)), rng.normal(0, 0.3, f)
-    ub, b, r = rng.normal(0, 0.3, n), 0.2, rng.integers(1, 11, n) / 2.0
-    regs = (0.02, 0.02, 0.02, 0.02)
-    want = sequential_chain(P, ub, r, q, b, 3.5, 0.01, regs, np.float32)
-    got = affine_chain(P, ub, r, q, b, 3.5, 0.01, regs, 64, np.float32)
-    for g, w in zip(got, want):
-        assert np.abs(np.asarray(g, np.float64) - np.asarray(w, np.float64)).max() < 2e-5
-
-
 def lookahead_chain(P, ub, r, q, b, gb, lr, regs, dtype):
     """The look-ahead form of the chain (bs_chain_kernel, round 4).  Blocks of B = 64 links; block i >= 1 takes its
     right-hand side from the state in front of block i - 1 and the errors of block i - 1:

@@ -64,29 +64,6 @@ def test_blocksolve_matches_sequential_oracle(min_rate, users, items, nnz, f, it
     assert max(diffs) <= 2e-6, diffs  # float rounding of re-associated sums; values are O(0.1 .. 1)
 
 
-@pytest.mark.parametrize("users,items,nnz,f,iters,rate,aff,head", [
-    (300, 120, 6000, 10, 70, 2.0, 1, 1),      # every hot chain of three blocks and more; crosses a schedule batch
-    (3000, 40, 30000, 100, 6, 1.0, 1, 1),     # three blocks a chain, the last one partial: one plain, two affine
-    (9000, 6, 40000, 100, 3, 1.0, 10, 9),     # ~24 blocks a chain: the default head, the ring of T' blocks behind it
-    (9000, 6, 40000, 124, 3, 1.0, 2, 2),      # the widest row the form takes (state + constant column = 126 <= 128)
-    (2000, 300, 40000, 128, 5, 0.5, 1, 1),    # wider: stays in the plain form
-    (9000, 12, 60000, 40, 4, 1.0, 8, 3),      # mixed: chains on both sides of the threshold
-    (9000, 3, 30000, 1, 3, 1.0, 1, 4),        # f = 1, ~47 blocks a chain
-    (20000, 300, 90000, 16, 3, 8.0, 3, 1),    # ~280 hot chains: more chains than compute units are left for builders
-])
-def test_blocksolve_affine_form_matches_sequential_oracle(min_rate, users, items, nnz, f, iters, rate, aff, head):
-    """cu2rec_blocksolve_affine_blocks / _head: long chains advanced with one mat-vec per block behind a plain head."""
-    min_rate(rate)
-    prev, prev_head = cu.api.blocksolve_affine_blocks(aff), cu.api.blocksolve_affine_head(head)
-    try:
-        tr, _ = synth.make_ratings(users, items, nnz, min_degree=3, seed=users + f)
-        model, state = _run_both(tr, f, iters)
-        assert max(_max_diffs(model, state)) <= 2e-6
-    finally:
-        cu.api.blocksolve_affine_blocks(prev)
-        cu.api.blocksolve_affine_head(prev_head)
-
-
 @pytest.mark.parametrize("users,items,nnz,f,iters,rate,la", [
     (300, 120, 6000, 10, 70, 2.0, 1),       # every chain of two blocks and more; crosses a schedule batch
     (3000, 40, 30000, 100, 6, 1.0, 1),      # three blocks a chain, the last one partial
@@ -210,34 +187,6 @@ def test_blocksolve_full_shape_ml20m_1000_iterations_within_1e4_of_oracle():
         assert abs(got["mae"] - want["mae"]) <= 1e-4, order
         diffs = _max_diffs(model, (P, Q, ub, ib))
         assert max(diffs) <= 1e-3, (order, diffs)
-
-
-def test_blocksolve_affine_form_full_shape_ml20m_against_the_ordered_mode():
-    """The opt-in affine form at BASELINE.json configs[2]'s full shape (ML-20M shape, f=100): chains of 24 blocks and more run
-    their first 8 blocks in the plain form and the rest through maps built beside them (cu2rec_blocksolve_affine_blocks / _head).
-    72 iterations (a schedule batch is crossed) against the ordered mode -- the sequential result bit for bit
-    (tests/test_gpu_parity.py) -- on the same sample stream: every parameter within 5e-6, and not equal to the plain
-    block-solve result bit for bit (the form did run)."""
-    import bench
-    tr, _ = bench.load_dataset("ml-20m", 20240917, 0, lambda: None)
-    f, iters = 100, 72
-    d_tr = cu.DeviceCSR(tr)
-    assert d_tr.blocksolve_items() > 0
-    exact = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
-    exact.sgd(d_tr, HYPER, 42, 0, iters, mode="ordered")
-    plain = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
-    plain.sgd(d_tr, HYPER, 42, 0, iters, mode="blocksolve")
-    prev, prev_head = cu.api.blocksolve_affine_blocks(24), cu.api.blocksolve_affine_head(8)
-    try:
-        model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
-        model.sgd(d_tr, HYPER, 42, 0, iters, mode="blocksolve")
-    finally:
-        cu.api.blocksolve_affine_blocks(prev)
-        cu.api.blocksolve_affine_head(prev_head)
-    want = exact.download()
-    diffs = [float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(model.download(), want)]
-    assert max(diffs) <= 5e-6, diffs
-    assert any(not np.array_equal(g, w) for g, w in zip(model.download(), plain.download())), "the affine form did not run"
 
 
 def test_blocksolve_lookahead_form_full_shape_ml20m_against_the_ordered_mode():
@@ -453,7 +402,10 @@ print("OK %%.3e" %% max(float(np.abs(g.astype(np.float64) - w).max()) for g, w i
 def _run_fault_script(dbg):
     import subprocess
     import sys
-    env = dict(os.environ, CU2REC_BS_DBG=str(dbg), CU2REC_BS_WAIT_S="0.02")
+    # (the fault injection is compiled only into the test build of the library: make test-hooks -> build/test/libcu2rec_amd_hooks.so)
+    hooks = os.path.join(ROOT, "build", "test", "libcu2rec_amd_hooks.so")
+    assert os.path.exists(hooks), "build/test/libcu2rec_amd_hooks.so is missing: run __graft_entry__.build()"
+    env = dict(os.environ, CU2REC_BS_DBG=str(dbg), CU2REC_BS_WAIT_S="0.02", CU2REC_AMD_LIB=hooks)
     res = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
@@ -477,7 +429,7 @@ def test_blocksolve_gate_that_never_opens_only_costs_time():
     assert float(last.split()[1]) <= 2e-6, last
 
 
-_PIPE_SCRIPT = r"""
+_TOPOLOGY_SCRIPT = r"""
 import sys
 import numpy as np
 sys.path.insert(0, %(root)r)
@@ -505,15 +457,16 @@ print("OK %%.3e" %% worst)
 """
 
 
-def test_blocksolve_pipelined_topology_matches_sequential_oracle():
-    """The opt-in pipelined launch topology (CU2REC_BS_PIPE=1: phase 3 as persistent workgroups beside phase 2, fed block by block through
-    the chains' progress words; the join in phase 2's launch): plain and look-ahead chains, short and long, a row width it does not take
-    (f = 200: falls back to phase 3 behind phase 2), more chains than CUs -- each against the sequential oracle.  In a process of its own:
+def test_blocksolve_event_fork_and_join_matches_sequential_oracle():
+    """The launch topology a rocprofv3 counter pass gets (CU2REC_BS_GATE=0; the library takes it by itself when it sees
+    ROCPROF_COUNTER_COLLECTION): the side stream forked by an event on phase 1's completion signal and joined by an event wait in front
+    of the next phase 1, instead of the gate kernel and the device-side join of the default.  Same kernels, same results: plain and
+    look-ahead chains, short and long, wide rows, more chains than CUs -- each against the sequential oracle.  In a process of its own:
     the setting is read once."""
     import subprocess
     import sys
-    env = dict(os.environ, CU2REC_BS_PIPE="1")
-    res = subprocess.run([sys.executable, "-c", _PIPE_SCRIPT % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+    env = dict(os.environ, CU2REC_BS_GATE="0")
+    res = subprocess.run([sys.executable, "-c", _TOPOLOGY_SCRIPT % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:]
     last = res.stdout.strip().splitlines()[-1]

@@ -172,24 +172,6 @@ def test_sgd_hogwild_exact_when_no_item_is_shared():
         np.testing.assert_array_equal(g, w)
 
 
-def test_sgd_hogwild_blocked_launches():
-    """Opt-in launch blocking (k updates per user per launch, user row in registers): with no shared items it is
-    still the sequential result bit for bit, including a remainder block; the knob restores to 1."""
-    n, f = 3000, 50
-    rng = np.random.RandomState(1)
-    m = cu.HostCSR(np.arange(n + 1), rng.permutation(n), rng.randint(1, 6, n).astype(np.float32), n, n, 3.0)
-    P, Q, ub, ib = orc.init_model(n, n, f)
-    model = cu.Model(n, n, f, 3.0)
-    assert cu.lib().cu2rec_hogwild_iters_per_launch(4) == 1
-    try:
-        model.sgd(cu.DeviceCSR(m), HYPER, 42, 0, 10, mode="hogwild")  # blocks of 4, 4, 2
-    finally:
-        assert cu.lib().cu2rec_hogwild_iters_per_launch(1) == 4
-    orc.sgd_iterations(_as_orc(m), P, Q, ub, ib, 3.0, HYPER, 42, 0, 10, dot_order=orc.DOT_TREE16)
-    for g, w in zip(model.download(), (P, Q, ub, ib)):
-        np.testing.assert_array_equal(g, w)
-
-
 def test_factor_range_limits():
     """n_factors up to 512 is compiled in (J = 8 slots per lane); beyond that the library refuses, loudly."""
     tr, _ = _small_set(users=60, items=40, nnz=600, seed=13)
@@ -345,54 +327,41 @@ def test_sgd_ordered_bit_exact_vs_oracle(f, iters):
         np.testing.assert_array_equal(g, w, err_msg=name)
 
 
-@pytest.mark.parametrize("segmented,tile", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_sgd_ordered_schedule_forms_give_the_same_result(segmented, tile):
-    """The schedule of a batch can be built in four ways (keys per sample or per rating row x one sort of the whole batch or one
-    segment per iteration: CU2REC_SCHED_SEGMENTED / CU2REC_SCHED_KEYS_TILE, read once per process; both on is the default and what
-    every other test runs).  Each of the four, in a process of its own: the ordered mode -- and the block-solve mode's
-    plan, which is built from the same arrays -- against the oracle on a set with empty users, rows above 2,048 ratings (the
-    row-reading kernel's gather fallback) and 70 iterations (two batches), bit for bit / within 2e-6."""
-    code = r"""
-import numpy as np
-import cu2rec_amd as cu
-from cu2rec_amd import synth
-from oracle import oracle as orc
-tr, _ = synth.make_ratings(700, 3000, 60000, min_degree=3, seed=9)
-indptr = tr.indptr.copy()                       # users 100..139 lose their ratings
-lo, hi = indptr[100], indptr[140]
-indptr[100:141] = lo
-indptr[141:] -= hi - lo
-indices, data = np.delete(tr.indices, np.s_[lo:hi]), np.delete(tr.data, np.s_[lo:hi])
-rng = np.random.RandomState(3)                  # user 7 rates 2,500 items: above the row-reading kernel's 2,048
-l7, h7 = indptr[7], indptr[8]
-big_i = np.arange(2500, dtype=indices.dtype)
-big_r = (rng.randint(1, 11, size=2500) * 0.5).astype(data.dtype)
-indices = np.concatenate([indices[:l7], big_i, indices[h7:]])
-data = np.concatenate([data[:l7], big_r, data[h7:]])
-indptr[8:] += 2500 - (h7 - l7)
-tr = cu.HostCSR(indptr, indices, data, tr.rows, tr.cols, float(data.mean()))
-assert (np.diff(tr.indptr) > 2048).any() and (np.diff(tr.indptr) == 0).any()
-hyper, f, iters = (0.01, 0.02, 0.02, 0.02, 0.02), 20, 70
-o = orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias)
-state = orc.init_model(tr.rows, tr.cols, f)
-orc.sgd_iterations(o, *state, tr.global_bias, hyper, 42, 0, iters, dot_order=orc.DOT_TREE16)
-d = cu.DeviceCSR(tr)
-m = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
-m.sgd(d, hyper, 42, 0, iters, mode="ordered")
-for g, w in zip(m.download(), state):
-    assert np.array_equal(g, w)
-cu.api.blocksolve_min_rate(2.0)
-d = cu.DeviceCSR(tr)
-assert d.blocksolve_items() > 0
-m = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
-m.sgd(d, hyper, 42, 0, iters, mode="blocksolve")
-assert max(float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(m.download(), state)) <= 2e-6
-print("ok")
-"""
-    env = dict(os.environ, CU2REC_SCHED_SEGMENTED=str(segmented), CU2REC_SCHED_KEYS_TILE=str(tile), PYTHONPATH=ROOT)
-    out = subprocess.run([os.sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600,
-                         cwd=ROOT)
-    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
+def test_sgd_ordered_schedule_with_empty_users_and_rows_above_2048_ratings():
+    """The schedule's corner cases in one set: users without ratings inside the range, a rating row above 2,048 ratings (the
+    row-reading key kernel's gather fallback) and 70 iterations (two windows).  The ordered mode against the oracle bit for bit, and
+    the block-solve mode -- whose plan is built from the same sorted arrays -- within 2e-6."""
+    tr, _ = synth.make_ratings(700, 3000, 60000, min_degree=3, seed=9)
+    indptr = tr.indptr.copy()                       # users 100..139 lose their ratings
+    lo, hi = indptr[100], indptr[140]
+    indptr[100:141] = lo
+    indptr[141:] -= hi - lo
+    indices, data = np.delete(tr.indices, np.s_[lo:hi]), np.delete(tr.data, np.s_[lo:hi])
+    rng = np.random.RandomState(3)                  # user 7 rates 2,500 items: above the row-reading kernel's 2,048
+    l7, h7 = indptr[7], indptr[8]
+    big_i = np.arange(2500, dtype=indices.dtype)
+    big_r = (rng.randint(1, 11, size=2500) * 0.5).astype(data.dtype)
+    indices = np.concatenate([indices[:l7], big_i, indices[h7:]])
+    data = np.concatenate([data[:l7], big_r, data[h7:]])
+    indptr[8:] += 2500 - (h7 - l7)
+    tr = cu.HostCSR(indptr, indices, data, tr.rows, tr.cols, float(data.mean()))
+    assert (np.diff(tr.indptr) > 2048).any() and (np.diff(tr.indptr) == 0).any()
+    f, iters = 20, 70
+    state = orc.init_model(tr.rows, tr.cols, f)
+    orc.sgd_iterations(_as_orc(tr), *state, tr.global_bias, HYPER, 42, 0, iters, dot_order=orc.DOT_TREE16)
+    m = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    m.sgd(cu.DeviceCSR(tr), HYPER, 42, 0, iters, mode="ordered")
+    for g, w in zip(m.download(), state):
+        np.testing.assert_array_equal(g, w)
+    prev = cu.api.blocksolve_min_rate(2.0)
+    try:
+        d = cu.DeviceCSR(tr)
+        assert d.blocksolve_items() > 0
+        m = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+        m.sgd(d, HYPER, 42, 0, iters, mode="blocksolve")
+    finally:
+        cu.api.blocksolve_min_rate(prev if prev > 0 else -1.0)
+    assert max(float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(m.download(), state)) <= 2e-6
 
 
 def test_sgd_ordered_calls_of_any_length_share_schedule_windows():
@@ -729,36 +698,3 @@ def test_two_logical_shards_on_one_gpu_match_the_oracle():
         np.testing.assert_array_equal(gub, oub[k][u0:u1])
         np.testing.assert_array_equal(gQ, Qb)
         np.testing.assert_array_equal(gib, ibb)
-
-
-def test_ordered_persistent_launch_is_the_oracle_bit_for_bit():
-    """CU2REC_ORDERED_PERSISTENT=1 (opt-in; read once per process, hence a process of its own): a small set's ordered iterations as
-    ONE persistent launch per schedule batch, a grid barrier where the kernel boundaries were (sgd_ordered_persistent_kernel).  70
-    iterations (two batches) of a 3,000-user set with popular items (two-wave chains AND the walk): every parameter equal to the
-    sequential oracle's bit for bit -- a stale user row behind a barrier would change bits."""
-    import subprocess
-    import sys
-    script = r"""
-import sys
-import numpy as np
-sys.path.insert(0, %r)
-import cu2rec_amd as cu
-from cu2rec_amd import synth
-from cu2rec_amd._lib import check, lib
-from oracle import oracle as orc
-tr, _ = synth.make_ratings(3000, 40, 30000, min_degree=3, seed=77)
-f, hyper = 50, (0.01, 0.02, 0.02, 0.02, 0.02)
-model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
-d = cu.DeviceCSR(tr)
-model.sgd(d, hyper, 42, 0, 70, mode="ordered")
-model.sgd(d, hyper, 42, 70, 5, mode="ordered")
-check(lib().cu2rec_check_faults())
-state = orc.init_model(tr.rows, tr.cols, f)
-orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias), *state, tr.global_bias, hyper, 42, 0, 75,
-                   dot_order=orc.DOT_TREE16)
-assert lib().cu2rec_ordered_persistent_launches() >= 3, "the persistent form did not run"
-print("EQUAL" if all(np.array_equal(g, w) for g, w in zip(model.download(), state)) else "DIFFERENT")
-""" % ROOT
-    env = dict(os.environ, CU2REC_ORDERED_PERSISTENT="1")
-    res = subprocess.run([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-    assert res.returncode == 0 and res.stdout.strip().splitlines()[-1] == "EQUAL", res.stdout[-2000:]

@@ -18,7 +18,7 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 
 HYPER = (0.01, 0.02, 0.02, 0.02, 0.02)
-OFF, AUTO, FORCE, LOCAL = 0, 1, 2, 3
+OFF, AUTO, FORCE = 0, 1, 2
 
 
 class resident_policy:
@@ -275,30 +275,3 @@ def test_resident_nobody_has_ratings(cols):
         model.sgd(cu.DeviceCSR(m), HYPER, 42, 0, 6, mode="hogwild")
     for b, a in zip(before, model.download()):
         np.testing.assert_array_equal(a, b)
-
-
-@pytest.mark.parametrize("f,users,iters", [(50, 6040, 12), (100, 17311, 8), (100, 900, 6), (128, 18400, 6), (64, 30000, 6),
-                                           (200, 8000, 5)])
-def test_single_xcd_launch_bit_exact_across_its_barrier(f, users, iters):
-    """Policy 3: a set that fits the CUs of ONE XCD runs on the 32 workgroups that share workgroup 0's XCD (the other 224 of
-    the cooperative launch leave after the census); its barrier has no L2 write-back -- one L2 serves everybody -- but still
-    invalidates the L1s.  Same criterion as above: on a collision-free set every stale item row would change bits.
-    (6,040 users = the ML-1M shape: 6 rows per group; 17,311 = an eighth of ML-20M: 17 rows per group; 18,400 users at
-    f = 128: 18 per group, the register limit; 30,000 at f = 64 use LDS rows as well.)"""
-    m = _collision_free_set(users, 2 * users + 64, 4, 3, iters, seed=users + f, empty_every=0 if users < 1000 else 53)
-    import ctypes as C
-    blocks, rows = C.c_int(0), C.c_int(0)
-    with resident_policy(LOCAL):
-        assert cu.lib().cu2rec_hogwild_resident_plan(users, f, iters, C.byref(blocks), C.byref(rows)) == 1
-        assert blocks.value == 32 and rows.value * 32 * 32 >= users
-    _run_and_compare(m, f, 3, iters, LOCAL)
-    _run_and_compare(m, f, 3, iters, LOCAL, chunks=[iters - 2, 2])
-
-
-def test_single_xcd_policy_uses_the_whole_chip_when_one_xcd_is_too_small():
-    m = _collision_free_set(60000, 120064, 4, 0, 5, seed=77, empty_every=41)
-    import ctypes as C
-    blocks = C.c_int(0)
-    with resident_policy(LOCAL):
-        assert cu.lib().cu2rec_hogwild_resident_plan(60000, 100, 5, C.byref(blocks), None) == 1 and blocks.value > 32
-    _run_and_compare(m, 100, 0, 5, LOCAL)

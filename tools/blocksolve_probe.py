@@ -19,8 +19,6 @@ def main():
     ap.add_argument("--factors", type=int, default=100)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--rate", type=float, default=0.0)
-    ap.add_argument("--affine", type=int, default=-1, help="chains of at least this many blocks take the affine form (0: off)")
-    ap.add_argument("--head", type=int, default=0, help="blocks of such a chain in the plain form first")
     ap.add_argument("--skip-small", action="store_true")
     ap.add_argument("--skip-big", action="store_true")
     ap.add_argument("--stamps", action="store_true", help="wavefront timelines of one block-solve iteration")
@@ -30,10 +28,6 @@ def main():
     from oracle import oracle as orc
     import bench
     hyper = (0.01, 0.02, 0.02, 0.02, 0.02)
-    if args.affine >= 0:
-        api.blocksolve_affine_blocks(args.affine)
-    if args.head > 0:
-        api.blocksolve_affine_head(args.head)
     if not args.skip_small:
         for users, items, nnz, f, iters, rate in ((300, 120, 6000, 10, 5, 2.0), (300, 120, 6000, 100, 70, 2.0),
                                                   (3000, 40, 30000, 100, 6, 1.0), (3000, 40, 30000, 50, 6, 1e9),

@@ -4,9 +4,8 @@ sequential (mf_sequential.cu) trajectory -- the parity tests show it bit-identic
 as the reference curve here; this tool itself never touches oracle/.
 
 usage: tools/convergence_study.py [--workload ml-1m] [--factors 50] [--iters 2000] [--every 250]
-                                  [--modes hogwild,hogwild-streaming,hogwild:4,ordered]
-       hogwild = the default policy (resident launches when the rows fit), hogwild-streaming = one launch per iteration,
-       mode:k = k iterations per Hogwild launch without a barrier (opt-in blocking)
+                                  [--modes hogwild,hogwild-streaming,ordered]
+       hogwild = the default policy (resident launches when the rows fit), hogwild-streaming = one launch per iteration
 """
 import argparse
 import json
@@ -36,10 +35,6 @@ def main():
     d_tr, d_te = cu.DeviceCSR(train), cu.DeviceCSR(test)
     out = {"workload": args.workload, "f": f, "hyper": hyper, "iters": args.iters, "curves": {}}
     for mode in args.modes.split(","):
-        block = 1
-        if ":" in mode:  # e.g. hogwild:4 = Hogwild with 4 iterations per launch
-            mode, block = mode.split(":")[0], int(mode.split(":")[1])
-        cu.lib().cu2rec_hogwild_iters_per_launch(block)
         label = mode
         prev_policy = cu.lib().cu2rec_hogwild_resident(-1)
         if mode == "hogwild-streaming":  # one launch per iteration, user rows through HBM (CU2REC_RESIDENT=0)
@@ -53,9 +48,8 @@ def main():
             r = model.loss(d_te)
             t_sgd += time.perf_counter() - t0
             curve.append((it + args.every, r["rmse"], model.loss(d_tr)["rmse"]))
-        cu.lib().cu2rec_hogwild_iters_per_launch(1)
         cu.lib().cu2rec_hogwild_resident(prev_policy)
-        mode = label if block == 1 else "%s_x%d" % (label, block)
+        mode = label
         out["curves"][mode] = {"points": curve, "seconds": t_sgd}
         print(mode, "%.2fs" % t_sgd, " ".join("%d:%.5f" % (a, b) for a, b, _ in curve), flush=True)
     print(json.dumps(out))
