@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
     extern __shared__ float4 bs_smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = static_cast<int>(blockIdx.x) - it.la_grid;  // (the first la_grid workgroups of the launch: the cross blocks)
+    __builtin_amdgcn_s_setprio(2);  // (above the walk beside us and the schedule's kernels: this launch is on the iteration's critical path)
     WaveStamp stamp(it);
     // (every workgroup counts itself through, used or not: the side stream's gate waits for the whole grid)
     struct Through {
@@ -597,6 +598,7 @@ __device__ __forceinline__ void solve_chain(const SgdArgs &a, const BsIteration 
 
     if (tid >= 256) {
         // ------------------------------------------------------------------------------------------ loader
+        __builtin_amdgcn_s_setprio(2);
         constexpr int NLT = SW;  // float4 per loader thread and block: slots tp, tp + 4, ...
         const int lt = tid - 256, tr = lt >> 2, tp = lt & 3;
         auto load_val = [&](int t) -> uint64_t { return it.vals[begin + min(kB * t + tr, len - 1)]; };
@@ -982,6 +984,7 @@ __device__ __forceinline__ void chain_lookahead(const SgdArgs &a, const BsIterat
         // registers.  Every load and store is unconditional (clamped addresses, a sink in LDS for the surplus lanes): a branch
         // around a load makes the compiler wait for everything in flight.
         const int w = wave - 4;
+        __builtin_amdgcn_s_setprio(2);
         unsigned long long wt[2] = {0, 0};
         constexpr int NQ = (NSM + 3) / 4;
         const int idx0 = w * kB * NQ + lane;
@@ -1402,6 +1405,7 @@ __device__ __forceinline__ void update_block(const SgdArgs &a, const BsIteration
 __global__ __launch_bounds__(64 * kUpdMaxWaves) void bs_update_kernel(SgdArgs a, BsIteration it, int nwaves) {
     const int g = blockIdx.x;
     WaveStamp stamp(it);
+    __builtin_amdgcn_s_setprio(2);
     if (g == it.max_blocks) {  // the extra workgroup of the launch (side_seq set)
         if (threadIdx.x == 0) await_iteration_end(it);
         return;

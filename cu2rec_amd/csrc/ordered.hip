@@ -606,6 +606,9 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
                                                              const int *__restrict__ item_of_rank,
                                                              uint32_t item_mask, int n_hot,
                                                              int hot_blocks, int rank_lo, const int *__restrict__ ranges) {
+    // above the schedule's kernels (priority 0), which run BESIDE the iterations: where a wavefront of theirs shares a SIMD with one
+    // of an iteration's, the iteration's goes first (a kernel ends with its slowest workgroup: profiles/r05_handwritten_sort_experiment.txt)
+    __builtin_amdgcn_s_setprio(1);
     if (static_cast<int>(blockIdx.x) < hot_blocks) {
         // two-wave form for every row width: 32 lanes x 1 slot when 65 <= ld <= 128, else 16 lanes x J slots
         run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, n_hot, item_of_rank, rank_lo, ranges);

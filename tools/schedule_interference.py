@@ -21,7 +21,7 @@ def main():
             s, e = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
             if "bs_gram" in name:
                 gram.append(s)
-            elif any(k in name for k in ("schedule_keys", "radix_sort", "bs_plan", "chain_ranges", "RadixSort", "onesweep")):
+            elif any(k in name for k in ("schedule_keys", "radix_sort", "bs_plan", "chain_ranges", "RadixSort", "onesweep", "sched_sort")):
                 sched.append((s, e, name))
     gram.sort()
     sched.sort()
@@ -45,7 +45,7 @@ def main():
         print("  excess over the quiet mean: %.1f us per batch of 64 iterations = %.2f us per iteration"
               % ((loud.mean() - quiet.mean()) * len(loud) / max(len(period) / 64.0, 1e-9), (loud.mean() - quiet.mean()) * len(loud) / len(period)))
     # by kind of schedule kernel: iterations that contain (part of) one of that kind
-    kinds = {"keys": ("schedule_keys",), "sort": ("radix_sort", "RadixSort", "onesweep"), "ranges / plan": ("chain_ranges", "bs_plan")}
+    kinds = {"keys": ("schedule_keys",), "sort": ("radix_sort", "RadixSort", "onesweep", "sched_sort"), "ranges / plan": ("chain_ranges", "bs_plan")}
     for kind, pats in kinds.items():
         mark = np.zeros(len(period), dtype=bool)
         t_kind = 0.0

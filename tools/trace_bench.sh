@@ -13,5 +13,6 @@ stats=$(find $O/raw -name '*kernel_stats.csv' | head -1)
 cp $stats $O/kernel_stats.csv
 python3 $R/tools/iteration_timeline.py $trace ${CAP:-100} > $O/timeline.txt 2>&1
 python3 $R/tools/schedule_interference.py $trace --skip ${SKIP:-50} > $O/interference.txt 2>&1
+python3 $R/tools/kernel_overlap.py $trace ${OVERLAP:-sched_sort} > $O/overlap.txt 2>&1
 rm -rf $O/raw
-cat $O/timeline.txt $O/interference.txt
+cat $O/timeline.txt $O/interference.txt $O/overlap.txt
