@@ -8,6 +8,8 @@ int(n * (1 - test_ratio)) of them for training, both halves stably sorted by use
   python -m cu2rec_amd.prep map    ratings.csv            -> ratings_mapped.csv   (preprocessing/map_items.py:21-89)
   python -m cu2rec_amd.prep split  ratings_mapped.csv     -> *_train.csv, *_test.csv (split_to_test_train.py:39-78)
   python -m cu2rec_amd.prep config out.cfg [--iters ...]  -> 9-field config       (create_config.py:10-32)
+  python -m cu2rec_amd.prep map-netflix train.txt test.txt -> ratings_mapped_train.csv, ratings_mapped_test.csv next to train.txt
+                                                                                  (map_netflix.py:9-28)
 """
 import argparse
 import os
@@ -58,6 +60,54 @@ def map_ids(src, dst=None):
     return dst, int(user.max(initial=0)), int(item.max(initial=0)), len(user)
 
 
+def _read_netflix(path):
+    """The raw Netflix split files (map_netflix.py:9-13): no header, `user item  rating` separated by single spaces -- two in front
+    of the rating, so the rating is the FOURTH field of a line split at every space."""
+    users, items, ratings = [], [], []
+    with open(path) as fh:
+        for line in fh:
+            parts = line.rstrip("\r\n").split(" ")
+            if len(parts) < 4 or not parts[0]:
+                continue
+            users.append(int(parts[0]))
+            items.append(int(parts[1]))
+            ratings.append(float(parts[3]))
+    return np.asarray(users, np.int64), np.asarray(items, np.int64), np.asarray(ratings, np.float64)
+
+
+def map_netflix(train_src, test_src, train_dst=None, test_dst=None):
+    """map_netflix.py:15-28: ONE id mapping for both files, built from the training file in first-seen order; test rows whose user or
+    item the training file never names are dropped (add_missing=False, map_items.py:39-52); both outputs stably sorted by user."""
+    tu, ti, tr = _read_netflix(train_src)
+    uniq_u, first_u = np.unique(tu, return_index=True)
+    uniq_i, first_i = np.unique(ti, return_index=True)
+    id_u = np.empty(len(uniq_u), np.int64)
+    id_u[np.argsort(first_u, kind="stable")] = np.arange(1, len(uniq_u) + 1)
+    id_i = np.empty(len(uniq_i), np.int64)
+    id_i[np.argsort(first_i, kind="stable")] = np.arange(1, len(uniq_i) + 1)
+    su, si, sr = _read_netflix(test_src)
+    pu, pi = np.searchsorted(uniq_u, su), np.searchsorted(uniq_i, si)
+    known_u = (pu < len(uniq_u)) & (uniq_u[np.minimum(pu, max(len(uniq_u) - 1, 0))] == su) if len(uniq_u) else np.zeros(len(su), bool)
+    known_i = (pi < len(uniq_i)) & (uniq_i[np.minimum(pi, max(len(uniq_i) - 1, 0))] == si) if len(uniq_i) else np.zeros(len(si), bool)
+    # (the reference looks the user up first and skips the row at once: a row with an unknown user AND an unknown item counts as a user)
+    missing_users, missing_items = int((~known_u).sum()), int((known_u & ~known_i).sum())
+    if missing_users:
+        print("Skipped %d rows because of missing users" % missing_users)
+    if missing_items:
+        print("Skipped %d rows because of missing items" % missing_items)
+    keep = known_u & known_i
+    base = os.path.dirname(os.path.abspath(train_src))
+    train_dst = train_dst or os.path.join(base, "ratings_mapped_train.csv")
+    test_dst = test_dst or os.path.join(base, "ratings_mapped_test.csv")
+    mu, mi = id_u[np.searchsorted(uniq_u, tu)], id_i[np.searchsorted(uniq_i, ti)]
+    order = np.argsort(mu, kind="stable")
+    _write(train_dst, mu[order], mi[order], tr[order])
+    mu, mi, mr = id_u[pu[keep]], id_i[pi[keep]], sr[keep]
+    order = np.argsort(mu, kind="stable")
+    _write(test_dst, mu[order], mi[order], mr[order])
+    return train_dst, test_dst
+
+
 def split(src, test_fraction=0.2, seed=42, train_dst=None, test_dst=None, keep_users=False):
     """split_to_test_train.py:39-49,69-78 (split_true): random.seed(seed), ONE shuffle of all rows, the first
     int(n * (1 - test_fraction)) rows train, the rest test, both stably sorted by user -- the same files as the reference's
@@ -104,6 +154,9 @@ def main(argv=None):
     s.add_argument("--test-fraction", type=float, default=0.2)
     s.add_argument("--seed", type=int, default=42)
     s.add_argument("--keep-users", action="store_true", help="every user keeps at least one training rating (not the reference's behaviour)")
+    nf = sub.add_parser("map-netflix")
+    nf.add_argument("train")
+    nf.add_argument("test")
     c = sub.add_parser("config")
     c.add_argument("dst")
     c.add_argument("--iters", type=int, default=5000)
@@ -114,6 +167,8 @@ def main(argv=None):
     args = ap.parse_args(argv)
     if args.cmd == "map":
         print("%s: %d users, %d items, %d ratings" % map_ids(args.src, args.dst))
+    elif args.cmd == "map-netflix":
+        print("%s %s" % map_netflix(args.train, args.test))
     elif args.cmd == "split":
         print("%s %s" % split(args.src, args.test_fraction, args.seed, keep_users=args.keep_users))
     else:

@@ -10,6 +10,10 @@ child processes, on a small raw file this script makes up; only their OUTPUTS ar
   prep_ref_train.csv      preprocessing/split_to_test_train.py prep_ref_mapped.csv 0.2   (random.seed(42) shuffle, first 80 %,
   prep_ref_test.csv         both halves stably sorted by user)
   prep_ref_config.cfg     preprocessing/create_config.py -n 500 -f 50 -l 0.005 -s 7 -p 0.03 -q 0.04 -u 0.05 -i 0.06
+  prep_netflix_train.txt  made-up raw Netflix split files (`user item  rating`, no header; the test file names two users and an item
+  prep_netflix_test.txt     the training file does not)
+  prep_ref_netflix_train.csv, prep_ref_netflix_test.csv   preprocessing/map_netflix.py on those (run where its hard-wired relative
+                          paths point: ../data/datasets/netflix/)
 """
 import os
 import shutil
@@ -41,6 +45,26 @@ def make_raw(path):
             fh.write("%d,%d,%s,%d\n" % r)
 
 
+def make_netflix(train_path, test_path):
+    rng = np.random.RandomState(20241005)
+    users = [1488844, 822109, 885013, 30878, 823519, 893988, 124105, 1248029]
+    items = [1, 17770, 8, 30, 4500, 571, 175]
+    seen, rows = set(), []
+    while len(rows) < 48:
+        u, i = users[rng.randint(len(users))], items[rng.randint(len(items))]
+        if (u, i) not in seen:
+            seen.add((u, i))
+            rows.append((u, i, int(rng.randint(1, 6))))
+    with open(train_path, "w") as fh:
+        for u, i, r in rows:
+            fh.write("%d %d  %d\n" % (u, i, r))
+    test = [(rows[k][0], rows[(k * 7 + 3) % len(rows)][1], int(rng.randint(1, 6))) for k in range(0, 24, 2)]
+    test += [(2000000, 1, 4), (30878, 9999, 2), (2000001, 9999, 5), (822109, 8, 3)]  # unknown user, unknown item, both, known
+    with open(test_path, "w") as fh:
+        for u, i, r in test:
+            fh.write("%d %d  %d\n" % (u, i, r))
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("needs the reference tree at /root/reference (build container only)")
@@ -58,6 +82,16 @@ def main():
                          ("prep_raw_mapped_train.csv", "prep_ref_train.csv"), ("prep_raw_mapped_test.csv", "prep_ref_test.csv"),
                          ("c.cfg", "prep_ref_config.cfg")):
             shutil.copyfile(os.path.join(tmp, src), os.path.join(GOLD, dst))
+            print("wrote tests/golden/" + dst)
+        # map_netflix.py reads and writes ../data/datasets/netflix/ relative to the directory it is run in
+        nf = os.path.join(tmp, "data", "datasets", "netflix")
+        os.makedirs(nf)
+        os.makedirs(os.path.join(tmp, "pp"))
+        make_netflix(os.path.join(nf, "netflix_train.txt"), os.path.join(nf, "netflix_test.txt"))
+        subprocess.run([sys.executable, os.path.join(REF, "map_netflix.py")], check=True, cwd=os.path.join(tmp, "pp"))
+        for src, dst in (("netflix_train.txt", "prep_netflix_train.txt"), ("netflix_test.txt", "prep_netflix_test.txt"),
+                         ("ratings_mapped_train.csv", "prep_ref_netflix_train.csv"), ("ratings_mapped_test.csv", "prep_ref_netflix_test.csv")):
+            shutil.copyfile(os.path.join(nf, src), os.path.join(GOLD, dst))
             print("wrote tests/golden/" + dst)
 
 
