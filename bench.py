@@ -63,6 +63,29 @@ def load_dataset(name, seed, rank, barrier):
             HostCSR(z["te_indptr"], z["te_indices"], z["te_data"], rows, cols, gb))
 
 
+def host_description():
+    """CPU model of this box and the compilers behind the two CPU baselines."""
+    model, cores = "unknown", os.cpu_count()
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+
+    def version(cmd):
+        try:
+            return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=20).stdout.strip().splitlines()[0]
+        except Exception:  # (no compiler on the box: the binaries travelled prebuilt)
+            return "unavailable on this box (binary prebuilt in the build container)"
+    return {"cpu_model": model, "logical_cpus": cores,
+            "port_compiler": version(["gcc", "--version"]) + "; flags -std=c99 -O3 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile)",
+            "reference_compiler": version(["/opt/rocm/bin/hipcc", "--version"]) + "; hipify-perl + hipcc -std=c++14 host compile of the reference's unity "
+                                  "source (oracle/build_ref.py; the image has no nvcc)"}
+
+
 def cpu_baseline(train, test, f, hyper, budget_s=12.0):
     """Reference CPU twin (if its binary travelled) and the oracle port, on bounded samples."""
     from cu2rec_amd import synth
@@ -119,6 +142,7 @@ def cpu_baseline(train, test, f, hyper, budget_s=12.0):
                    "port": port}
     if not out:
         out = port
+    out["host"] = host_description()
     return out
 
 
@@ -133,8 +157,17 @@ SHARDED_TOLERANCE = {
     "north_star_bar": 1e-4, "meets_north_star_bar": "N <= 2 only"}
 
 # rocprofv3 --pmc summaries (tools/pmc_summary.py) of THIS workload and mode, if one is committed: (workload, factors, mode) -> file
-PMC_PROFILES = {("ml-20m", 100, "blocksolve"): "profiles/r04_pmc_blocksolve_ml20m_f100.json",
-                ("netflix", 128, "blocksolve"): "profiles/r04_pmc_blocksolve_netflix_f128.json"}
+def _latest(pattern):
+    """The newest round's committed file of that name (profiles/rNN_...), or None."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return os.path.relpath(found[-1], ROOT) if found else None
+
+
+PMC_PROFILES = {("ml-20m", 100, "blocksolve"): _latest("r0?_pmc_blocksolve_ml20m_f100.json"),
+                ("netflix", 128, "blocksolve"): _latest("r0?_pmc_blocksolve_netflix_f128.json")}
+KERNEL_STATS = {("ml-20m", 100, "blocksolve"): _latest("r0?_kernel_stats_blocksolve_ml20m_f100.csv"),
+                ("netflix", 128, "blocksolve"): _latest("r0?_kernel_stats_blocksolve_netflix_f128.csv")}
 # the kernels of one SGD iteration of a mode (the schedule kernels run once per batch of 64 iterations: counted per iteration below)
 ITERATION_KERNELS = {"blocksolve": ("bs_gram_kernel", "bs_solve_kernel", "bs_update_kernel", "sgd_ordered_kernel")}
 
@@ -162,6 +195,28 @@ def profile_traffic(workload, factors, mode):
     if not parts:
         return None, "%s lists none of the iteration's kernels" % rel
     return total, "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units, FETCH doubled; per launch: %s)" % (rel, ", ".join(parts))
+
+
+def profile_kernels(workload, factors, mode):
+    """Per kernel of one iteration, from the COMMITTED rocprofv3 summaries of this workload: average duration (kernel stats), HBM-side
+    bytes per launch (PMC passes, corrected as above), bytes / duration against the HBM peak.  None without both files."""
+    import csv
+    stats, pmc = KERNEL_STATS.get((workload, factors, mode)), PMC_PROFILES.get((workload, factors, mode))
+    if not stats or not pmc or not os.path.exists(os.path.join(ROOT, stats)) or not os.path.exists(os.path.join(ROOT, pmc)):
+        return None
+    with open(os.path.join(ROOT, pmc)) as fh:
+        counters = json.load(fh)
+    out = []
+    with open(os.path.join(ROOT, stats)) as fh:
+        for row in csv.DictReader(fh):
+            for name in ITERATION_KERNELS.get(mode, ()):
+                if name + "<" in row["Name"] or name + "(" in row["Name"]:
+                    us = float(row["AverageNs"]) / 1e3
+                    b = next((rec.get("hbm_bytes_per_launch_corrected") for k, rec in counters.items() if name + "<" in k or name + "(" in k), None)
+                    hit = next((rec.get("l2_hit_rate") for k, rec in counters.items() if name + "<" in k or name + "(" in k), None)
+                    out.append({"kernel": name, "avg_us": us, "calls": int(row["Calls"]), "hbm_bytes_per_launch": b, "l2_hit_rate": hit,
+                                "GBs": (b / (us * 1e-6) / 1e9) if b else None, "frac_of_hbm_peak": (b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if b else None})
+    return {"from": [stats, pmc], "kernels": out} if out else None
 
 
 def log(msg):
@@ -532,7 +587,7 @@ def main():
     if rank == 0:
         traffic, traffic_src = profile_traffic(args.workload, f, mode)
         kernels = {"blocksolve": "one block-solve iteration = bs_gram_kernel + bs_solve_kernel + bs_update_kernel, sgd_ordered_kernel beside them "
-                                 "(per-kernel durations: profiles/r04_kernel_stats_blocksolve_*.csv)",
+                                 "(per-kernel durations: profiles/rNN_kernel_stats_blocksolve_*.csv, newest round)",
                    "hogwild": "sgd_resident_kernel / sgd_hogwild_kernel", "ordered": "sgd_ordered_kernel", "serial": "sgd_serial_kernel"}
         line = {
             "metric": "ratings/sec (SGD updates/sec)", "value": value, "unit": "updates/s", "n_gpus": world,
@@ -552,6 +607,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_over_algorithmic": (traffic / (users_active * bytes_per_update)) if traffic else None,
                          "traffic_from_profile": traffic_src,
+                         "kernels": profile_kernels(args.workload, f, mode),
                          "kernel": kernels.get(mode, mode), "bytes_per_update": bytes_per_update,
                          "algorithmic_bytes": alg_bytes, "device_seconds": elapsed_dev,
                          "note": "algorithmic bytes of the timed region (rank 0's updates x (16 f + 32)) / its duration by HIP events on "

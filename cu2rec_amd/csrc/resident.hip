@@ -446,13 +446,10 @@ int variant_for(int j, int need, bool partial = false) {
     return best;
 }
 
-// Partial residency (CU2REC_RESIDENT_PARTIAL=0 switches it off: sets that do not fit stream, as before round 4) pays while a
-// fair share of the rows is resident: at most kMaxStreamedPerResident streamed users per resident one.
+// Partial residency pays while a fair share of the rows is resident: at most kMaxStreamedPerResident streamed users per resident
+// one (beyond that -- and with the policy off -- a set that does not fit streams, one launch per iteration).
 constexpr int kMaxStreamedPerResident = 3;
-bool resident_partial_allowed() {
-    static const bool on = !(std::getenv("CU2REC_RESIDENT_PARTIAL") && std::atoi(std::getenv("CU2REC_RESIDENT_PARTIAL")) == 0);
-    return on;
-}
+bool resident_partial_allowed() { return true; }
 
 struct DeviceState {
     bool ready = false;

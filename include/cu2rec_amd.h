@@ -250,8 +250,7 @@ int cu2rec_hogwild_resident_geometry(int n_rows, int n_factors, int n_cus, int *
  * runs as ONE launch per call -- of the users_per_group users of every group (cu2rec_hogwild_resident_geometry's figure INCLUDES the
  * streamed ones) the first users_per_group - s are resident as above, the other s streamed through the same pipeline, row in,
  * update, row out (the reference's loop is sgd.cu:22-75 either way).  Returns s for the geometry above: 0 = fully resident, > 0 = that
- * many streamed rows per group, -1 = no compiled form holds the set (one launch per iteration).  CU2REC_RESIDENT_PARTIAL=0
- * switches the partial forms off. */
+ * many streamed rows per group, -1 = no compiled form holds the set (one launch per iteration). */
 int cu2rec_hogwild_resident_streamed_rows(int n_rows, int n_factors, int n_cus);
 
 /* Workspace of CU2REC_SGD_ORDERED for one device CSR: item popularity ranks, key/value buffers of the
@@ -267,7 +266,17 @@ int cu2rec_sgd_update_ordered(cu2rec_schedule *schedule, const int *indptr, cons
                               uint64_t seed, uint64_t iter0, int n_iters, int update_items, int user_offset,
                               void *stream);
 
-/* cu2rec_sgd_update in CU2REC_SGD_BLOCKSOLVE mode on raw device pointers (same arguments as the ordered form). */
+/* cu2rec_sgd_update in CU2REC_SGD_BLOCKSOLVE mode on raw device pointers (same arguments as the ordered form).
+ * Launch topology: an iteration is phases 1-3 on `stream` and the other items' chains on a side stream of the schedule's, forked and
+ * joined on the DEVICE (a gate kernel, a signal kernel and one waiting workgroup: no event on the main stream).  UNDER A COUNTER PASS
+ * OF rocprofv3 (--pmc; the tool exports ROCPROF_COUNTER_COLLECTION) THE LIBRARY SWITCHES TO AN EVENT FORK / JOIN BY ITSELF: a counter
+ * pass serialises kernels across streams, and the device-side join would wait for a signal kernel the profiler has not let run.  Same
+ * kernels, same bytes, same results (tests/test_gpu_blocksolve.py runs both); 3-6 us per iteration slower, so a --pmc pass is for
+ * counters, never for timing.  CU2REC_BS_GATE=0 / 1 in the environment forces the event / device form.
+ * Environment knobs the library reads (all optional, read once per process): CU2REC_RESIDENT (Hogwild launch form), CU2REC_BLOCKSOLVE_RATE,
+ * CU2REC_BLOCKSOLVE_LOOKAHEAD, CU2REC_BS_GATE, CU2REC_BS_WAIT_S (block-solve mode), CU2REC_READER_THREADS, CU2REC_RATINGS_CACHE (ingest),
+ * CU2REC_COMM_TIMEOUT_S, CU2REC_MERGE_ADAPTIVE_C, CU2REC_RCCL_WORLD1 (sharded driver; the last one a debugging aid: a real one-rank
+ * communicator) -- ten in all; fault injection exists only in the test builds (make test-hooks). */
 int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, const int *indices, const float *data,
                                  int n_rows, int n_cols, float *P, int ldp, float *Q, int ldq, float *user_bias,
                                  float *item_bias, float global_bias, int n_factors, const cu2rec_hyper *hyper,
