@@ -1,6 +1,8 @@
-"""The C++ multi-GPU driver (cu2rec_amd/csrc/sharded.cpp) on ONE GPU (-m gpu): world 1, RCCL at world 1, and two ranks
+"""The C++ multi-GPU driver (cu2rec_amd/csrc/sharded.cpp) on ONE GPU (-m gpu): world 1, RCCL at world 1, two ranks
 sharing the GPU with the callback communicator (gloo through the host) -- against the CPU oracle running the same
-schedule with numpy doing the merge.  Real N = 2 / 4 / 8 runs are the driver's scaling bench."""
+schedule with numpy doing the merge -- and N = 2 / 4 / 8 ranks of the driver as threads of one process at the FULL
+BASELINE shapes (configs[3], configs[4]): fixed-iteration gaps per N and converged runs against SURVEY 8e's bar.
+Real N = 2 / 4 / 8 numbers over RCCL are the driver's scaling bench (tools/scale_preflight.py checks the plumbing first)."""
 import ctypes as C
 import os
 import sys
@@ -193,98 +195,187 @@ def test_bin_mf_g1_flag_and_sharded_cli_single_rank(tmp_path):
     assert outs[0] == outs[1]
 
 
-def _emulated_shards_gap(workload, f, iters, sync, n, merges=("adaptive",)):
-    """N user shards emulated on ONE GPU (N engines run one after the other, block-solve mode per shard, the merge arithmetic of the
-    driver's exchange in torch): test RMSE after `iters` iterations minus the unsharded = sequential result, per merge rule.  The
-    driver's own exchange (wire pack / ncclAllReduce / apply) is pinned against the oracle by the two-rank test above; this pins
-    the CONVERGENCE of the merge rule at BASELINE.json configs[3] / [4]'s shapes."""
-    import torch
+class _InProcessWorld:
+    """N ranks of the product's sharded driver as N threads of THIS process sharing the one GPU: every rank has its own cu2rec_comm
+    built on the callback communicator, and the callback below is the all-reduce -- each rank copies its device buffer to the host,
+    the buffers are added in rank order (the same bits on every rank) and copied back.  So ShardDriver's constructor (rates and
+    merge weights), wire_pack -> all-reduce -> wire_apply, the loss reduction and train() over all ranks run at FULL size; only the
+    transport under them is not RCCL (that is tools/scale_preflight.py's and the driver's scaling run's business)."""
+
+    def __init__(self, n):
+        import threading
+        self.n = n
+        self.slots = [None] * n
+        self.barrier = threading.Barrier(n)
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.errors = []
+
+    def allreduce_for(self, rank):
+        def allreduce(ctx, buf, count, is_double, stream):
+            try:
+                host = np.empty(count, np.float64 if is_double else np.float32)
+                if self.hip.hipMemcpy(host.ctypes.data, buf, host.nbytes, 2) != 0:  # (synchronous: behind the kernels that filled it)
+                    return 1
+                self.slots[rank] = host
+                self.barrier.wait(timeout=600)
+                total = self.slots[0].copy()
+                for k in range(1, self.n):
+                    total += self.slots[k]
+                self.barrier.wait(timeout=600)  # everybody has read the slots
+                return 0 if self.hip.hipMemcpy(buf, total.ctypes.data, total.nbytes, 1) == 0 else 1
+            except Exception as e:  # a broken barrier: another rank failed
+                self.errors.append(repr(e))
+                return 1
+        return allreduce
+
+    def run(self, fn):
+        """fn(rank, comm) on every rank; -> the ranks' results (raises what the first failing rank raised)."""
+        import threading
+        out, failed = [None] * self.n, []
+
+        def body(rank):
+            try:
+                comm = sharded.Comm(rank, self.n, allreduce=self.allreduce_for(rank))
+                out[rank] = fn(rank, comm)
+                comm.close()
+            except BaseException as e:
+                failed.append(e)
+                self.barrier.abort()
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if failed:
+            raise failed[0]
+        return out
+
+
+def _sharded_run(workload, f, n, merge="adaptive", sync=0, iters=0, converged_iters=0):
+    """The product's sharded driver on N shards of a BASELINE shape (in-process world above): block-solve per shard, `merge`,
+    exchange every `sync` iterations (0: one epoch).  iters > 0: cu2rec_shard_job_run for that many iterations at lr .01, then an
+    exchange; converged_iters > 0: cu2rec_train_sharded under the reference's schedule (check every 500, patience 2, decay 0.2).
+    -> (global test RMSE, exchanges, replicas identical, final learning rate)."""
     import bench
-    from cu2rec_amd.engine import DeviceRatings, Engine
-    from cu2rec_amd.sharded import plan_users
     train, test = bench.load_dataset(workload, 20240917, 0, lambda: None)
-    dev = torch.device("cuda", 0)
-
-    def test_rmse(engines, bounds):
-        ss = 0.0
-        for e, (u0, u1) in zip(engines, bounds):
-            ss += e.loss(DeviceRatings(test.slice_users(u0, u1), dev))["sum_sq"]
-        return (ss / test.nnz) ** 0.5
-
-    base = Engine(train.rows, train.cols, f, train.global_bias, device=dev)
-    base.sgd(DeviceRatings(train, dev), HYPER, 42, 0, iters, "blocksolve")
-    ref = test_rmse([base], [(0, train.rows)])
-    del base
     P0 = cu.initialize_normal_array(train.rows * f, f).reshape(train.rows, f)
     ub0 = cu.initialize_normal_array(train.rows, f)
-    b = plan_users(train.rows, n)
-    bounds = list(zip(b[:-1], b[1:]))
-    shards = [train.slice_users(u0, u1) for u0, u1 in bounds]
-    rates = np.stack([cu.api.item_update_rates(s) for s in shards]).astype(np.float64)
-    tot = rates.sum(0)
-    phi = lambda x: -np.expm1(-6.0 * x)
-    alpha = torch.tensor(np.where(tot > 0, phi(tot) / np.maximum(phi(rates).sum(0), 1e-300), 1.0), dtype=torch.float32, device=dev)
-    weights = torch.tensor(np.where(tot > 0, rates / np.maximum(tot, 1e-300), 1.0 / n), dtype=torch.float32, device=dev)
-    got = {}
-    for merge in merges:
-        engines = [Engine(u1 - u0, train.cols, f, train.global_bias, P=P0[u0:u1], user_bias=ub0[u0:u1], device=dev) for u0, u1 in bounds]
-        d = [DeviceRatings(s, dev) for s in shards]
-        Qb, ibb = engines[0].Q.clone(), engines[0].item_bias.clone()
-        it = 0
-        while it < iters:
-            k = min(sync, iters - it)
-            for e, dr, (u0, _) in zip(engines, d, bounds):
-                e.sgd(dr, HYPER, 42, it, k, "blocksolve", True, u0)
-            it += k
-            dQ = torch.stack([e.Q - Qb for e in engines])[:, :train.cols]
-            dib = torch.stack([e.item_bias - ibb for e in engines])[:, :train.cols]
-            if merge == "adaptive":
-                Qb[:train.cols] += alpha[:, None] * dQ.sum(0)
-                ibb[:train.cols] += alpha * dib.sum(0)
-            else:
-                Qb[:train.cols] += (weights[:, :, None] * dQ).sum(0)
-                ibb[:train.cols] += (weights * dib).sum(0)
-            for e in engines:
-                e.Q.copy_(Qb)
-                e.item_bias.copy_(ibb)
-        got[merge] = test_rmse(engines, bounds) - ref
-        del engines, d
-    return got
+    world = _InProcessWorld(n)
+
+    def rank_body(rank, comm):
+        u0, u1, tr, te = sharded.shard_of(train, test, rank, n)
+        model = cu.Model(u1 - u0, train.cols, f, train.global_bias, P=P0[u0:u1], user_bias=ub0[u0:u1])
+        d_tr, d_te = cu.DeviceCSR(tr), cu.DeviceCSR(te)
+        job = sharded.ShardJob(comm, model, d_tr, user_offset=u0, sync_every=sync, merge=merge)
+        lr, extra = HYPER[0], None
+        if converged_iters:
+            cfg = cu.default_config(total_iterations=converged_iters, n_factors=f, learning_rate=0.01, seed=42, P_reg=0.02, Q_reg=0.02,
+                                    user_bias_reg=0.02, item_bias_reg=0.02)
+            losses, _ = job.train(d_te, cfg, mode="blocksolve", verbose=False)
+            rmse, lr = float(losses[converged_iters - 1]), float(cfg.learning_rate)
+            extra = {"min": float(np.nanmin(losses)), "at": int(np.nanargmin(losses)) + 1,
+                     "checks": [(int(i) + 1, float(v)) for i, v in enumerate(losses) if np.isfinite(v)]}
+        else:
+            job.run(HYPER, 42, 0, iters, mode="blocksolve")
+            job.exchange()
+            rmse = job.loss(d_te)["rmse"]
+        info = job.info()
+        _, Q, _, ib = model.download()
+        job.close()
+        return rmse, info["exchanges"], Q, ib, lr, extra
+    res = world.run(rank_body)
+    assert not world.errors, world.errors
+    same = all(np.array_equal(res[0][2], r[2]) and np.array_equal(res[0][3], r[3]) for r in res[1:])
+    assert all(r[0] == res[0][0] for r in res), "the ranks disagree on the GLOBAL test RMSE"
+    _sharded_run.last_extra = res[0][5]
+    return res[0][0], res[0][1], same, res[0][4]
 
 
-def test_eight_shards_adaptive_merge_within_the_stated_tolerance_of_the_sequential_run():
-    """The acceptance tolerance of a user-sharded run: after 1,000 iterations of the ML-20M shape, f=100, the
-    test RMSE of N = 8 shards -- block-solve mode per shard, item deltas reconciled once per epoch (115 iterations) with the
-    driver's `adaptive` merge, delta = phi(r_total) / sum_k phi(r_k) * sum_k delta_k, phi(r) = 1 - exp(-6 r) -- stays within
-    6e-4 of the unsharded = sequential result (measured in round 2: +3.9e-4; `weighted`: +1.07e-3, pinned here as the bar the
-    adaptive merge must beat)."""
-    got = _emulated_shards_gap("ml-20m", 100, 1000, 115, 8, ("adaptive", "weighted"))
-    assert abs(got["adaptive"]) <= 6e-4, got
-    assert abs(got["adaptive"]) < abs(got["weighted"]), got
+def _unsharded(workload, f, iters=0, converged_iters=0):
+    """The N = 1 = sequential-semantics result of the same schedule (block-solve mode; test RMSE)."""
+    import bench
+    train, test = bench.load_dataset(workload, 20240917, 0, lambda: None)
+    d_tr, d_te = cu.DeviceCSR(train), cu.DeviceCSR(test)
+    if converged_iters:
+        cfg = cu.default_config(total_iterations=converged_iters, n_factors=f, learning_rate=0.01, seed=42, P_reg=0.02, Q_reg=0.02,
+                                user_bias_reg=0.02, item_bias_reg=0.02)
+        out = cu.train(d_tr, d_te, cfg, mode="blocksolve", verbose=False)
+        _unsharded.last_extra = {"min": float(np.nanmin(out[2])), "at": int(np.nanargmin(out[2])) + 1,
+                                 "checks": [(int(i) + 1, float(v)) for i, v in enumerate(out[2]) if np.isfinite(v)]}
+        return float(out[2][converged_iters - 1]), float(cfg.learning_rate)
+    model = cu.Model(train.rows, train.cols, f, train.global_bias)
+    model.sgd(d_tr, HYPER, 42, 0, iters, mode="blocksolve")
+    return model.loss(d_te)["rmse"], HYPER[0]
 
 
-def test_two_shards_adaptive_merge_meets_the_1e4_bar():
-    """BASELINE.json configs[3] at N = 2 (emulated): the sharded run's test RMSE after 1,000 iterations stays within the north
-    star's 1e-4 of the sequential result (measured: -1e-5)."""
-    got = _emulated_shards_gap("ml-20m", 100, 1000, 115, 2)
-    assert abs(got["adaptive"]) <= 1e-4, got
+_ML20M_1000 = {}
 
 
-def test_four_shards_adaptive_merge_is_outside_the_1e4_bar_by_this_much():
-    """BASELINE.json configs[3] at N = 4 (emulated): measured +1.7e-4 -- OUTSIDE the north star's 1e-4 (a sharded run reconciles the
-    item side once per epoch; it is not the sequential run), inside the stated tolerance of 3e-4 for N = 4.  No merge rule tried
-    brings N >= 4 under 1e-4 (exchanging more often does not help, the bias is in the merge)."""
-    got = _emulated_shards_gap("ml-20m", 100, 1000, 115, 4)
-    assert abs(got["adaptive"]) <= 3e-4, got
+def _ml20m_reference_1000():
+    if "v" not in _ML20M_1000:
+        _ML20M_1000["v"] = _unsharded("ml-20m", 100, iters=1000)[0]
+    return _ML20M_1000["v"]
 
 
-def test_eight_shards_netflix_f128_within_the_stated_tolerance():
-    """BASELINE.json configs[4] (Netflix shape, f=128, 8 shards, emulated): 660 iterations, exchange every 165 (one epoch): the
-    sharded run's test RMSE sits 1.2e-3 BELOW the sequential run's at that point of the trajectory (nearly every one of the 17,770
-    items is updated many times per iteration by every shard: the adaptive merge is the mean there).  Pinned: |gap| <= 1.6e-3, and
-    the sign."""
-    got = _emulated_shards_gap("netflix", 128, 660, 165, 8)
-    assert -1.6e-3 <= got["adaptive"] <= 0.0, got
+@pytest.mark.parametrize("n,accepted", [(2, 1e-4), (4, 3e-4), (8, 6e-4)])
+def test_sharded_driver_full_shape_ml20m_fixed_iterations(n, accepted):
+    """BASELINE.json configs[3] by the PRODUCT's driver at full size (ML-20M shape, f=100, N shards as N ranks of an in-process world:
+    ShardDriver's constructor, items_wire_pack / apply at 26,744 x 101 floats, the loss reduction): 1,000 iterations, one exchange per
+    epoch, `adaptive` merge, against the unsharded = sequential result at the same iteration.  Measured: N=2 -1e-5 (inside the north
+    star's 1e-4), N=4 +1.7e-4, N=8 +3.9e-4 (both OUTSIDE it, inside the tolerance stated per N: a sharded run reconciles the item side
+    once per epoch, it is not the sequential run).  Replicas bit-identical; the exchange count is the cadence's."""
+    rmse, exchanges, same, _ = _sharded_run("ml-20m", 100, n, iters=1000)
+    gap = rmse - _ml20m_reference_1000()
+    assert abs(gap) <= accepted, (n, gap)
+    assert same and exchanges == 1000 // 115 + 1, (same, exchanges)  # 8 in cadence (epoch = 115) + the one asked for at the end
+
+
+def test_sharded_driver_weighted_merge_is_the_bar_adaptive_beats_at_n8():
+    rmse_w, _, _, _ = _sharded_run("ml-20m", 100, 8, merge="weighted", iters=1000)
+    rmse_a, _, _, _ = _sharded_run("ml-20m", 100, 8, merge="adaptive", iters=1000)
+    ref = _ml20m_reference_1000()
+    assert abs(rmse_a - ref) < abs(rmse_w - ref), (rmse_a - ref, rmse_w - ref)  # measured +3.9e-4 against +1.07e-3
+
+
+def test_sharded_driver_converged_n8_ml20m_against_survey_8e_bar():
+    """SURVEY.md section 8e's own bar -- "converged test RMSE ... <= 1e-3 of N = 1" -- measured with the product's train() over all
+    ranks: cu2rec_train_sharded on 8 shards of the ML-20M shape (f=100) under the reference's schedule (8,000 iterations: the rate
+    decays six times, lr < 1e-5) against cu2rec_train on the whole set; both take their own patience decisions on their own GLOBAL
+    test RMSE.  The outcome, pinned either way (profiles/r05_sharded_converged.txt has N = 2 / 4 / 8):
+      * at the schedule's END the bar is NOT met: the sharded run freezes 7.7e-3 BELOW the unsharded one (0.81279 against 0.82048;
+        N = 2 / 4: -4.3e-3 / -3.5e-3) -- eight replicas reconciled once per epoch overfit more slowly, their test RMSE turns up a
+        check later, and where a run freezes under the patience rule depends on WHICH check its test RMSE turns at (the same
+        mechanism that puts converged Hogwild runs 2.5e-3 ... 8.3e-3 apart, test_gpu_blocksolve.py);
+      * at the BEST checkpoint (the minimum of the logged test RMSE, what a user would keep) it is met: -2.7e-4."""
+    ref, ref_lr = _unsharded("ml-20m", 100, converged_iters=8000)
+    ref_min = _unsharded.last_extra["min"]
+    rmse, exchanges, same, lr = _sharded_run("ml-20m", 100, 8, converged_iters=8000)
+    best = _sharded_run.last_extra["min"]
+    assert ref_lr < 1e-5 and lr < 1e-5, (ref_lr, lr)  # both have converged in the schedule's sense
+    assert same and exchanges >= 8000 // 115
+    assert abs(best - ref_min) <= 1e-3, (best, ref_min)
+    assert -1.2e-2 <= rmse - ref <= -1e-3, (rmse, ref)
+
+
+def test_sharded_driver_netflix_f128_n8_fixed_iterations_and_converged():
+    """BASELINE.json configs[4] by the product's driver (Netflix shape, f=128, 8 shards, wire 17,770 x 129 floats): (i) 660
+    iterations, exchange every epoch (165): the sharded run sits 1.2e-3 BELOW the sequential run at that point of the trajectory
+    (nearly every item is updated many times per iteration by every shard: the adaptive merge is the mean there) -- pinned with its
+    sign, |gap| <= 1.6e-3; (ii) CONVERGED under the reference's schedule (8,000 iterations, lr < 1e-5 on both): the end point 5.0e-3
+    below N = 1 (0.85052 against 0.85549), the best checkpoint 1.8e-3 ABOVE (0.84418 at 2,000 against 0.84242 at 1,500) -- both
+    OUTSIDE SURVEY 8e's 1e-3, pinned as measured."""
+    ref, _ = _unsharded("netflix", 128, iters=660)
+    rmse, exchanges, same, _ = _sharded_run("netflix", 128, 8, iters=660)
+    assert same and exchanges == 660 // 165 + 1
+    assert -1.6e-3 <= rmse - ref <= 0.0, rmse - ref
+    ref_c, ref_lr = _unsharded("netflix", 128, converged_iters=8000)
+    ref_min = _unsharded.last_extra["min"]
+    rmse_c, _, same_c, lr = _sharded_run("netflix", 128, 8, converged_iters=8000)
+    best = _sharded_run.last_extra["min"]
+    assert same_c and ref_lr < 1e-5 and lr < 1e-5, (ref_lr, lr)
+    assert -1e-2 <= rmse_c - ref_c <= -1e-3, (rmse_c, ref_c)
+    assert 0.0 <= best - ref_min <= 2.5e-3, (best, ref_min)
 
 
 def test_bench_self_launches_its_ranks(tmp_path):
