@@ -721,9 +721,11 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     float min_rate = blocksolve_min_rate_base();
     if (!blocksolve_min_rate_is_set()) {
         min_rate = std::max(30.f, min_rate * static_cast<float>(n_active) / 131072.f);
-        // no chain long enough to pay for three launches and two events per iteration: the ordered walk alone is faster
-        // (an eighth of the ML-20M shape, hottest item 247 updates per iteration: 40 against 53 us per iteration)
-        if (n_cols > 0 && rate[order[0]] < 350.0) min_rate = std::numeric_limits<float>::infinity();
+        // a small set (one GPU's shard of a strong-scaling run): with the hottest item between 150 and 350 expected updates per
+        // iteration a threshold of 60 still pays a little (an eighth of the ML-20M shape, hottest item 247: 32.5 us per iteration
+        // against 35.3 walking everything; thresholds 40 / 60 / 90 / 130 / 180: 32.6 / 32.5 / 33.7 / 37.5 / 41.4, round 5); below
+        // that no chain is long enough to pay for three launches per iteration and the mode IS the ordered walk (ML-1M shape)
+        if (n_cols > 0 && rate[order[0]] < 350.0) min_rate = rate[order[0]] >= 150.0 ? 60.f : std::numeric_limits<float>::infinity();
     }
     n_hot_bs = 0;
     while (n_hot_bs < n_cols && rate[order[n_hot_bs]] >= min_rate) ++n_hot_bs;

@@ -395,3 +395,15 @@ def test_bench_self_launches_its_ranks(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0
     assert line["config"]["sharded_run_tolerance"] is not None
+
+
+def test_scale_preflight_passes_at_one_rank():
+    """tools/scale_preflight.py, the plumbing check to run on an N-GPU box before the first scaling run, at the N this box has: a real
+    one-rank RCCL communicator through the library's binding, two exchanges, replica digests, bin/mf -g 1."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_preflight.py"), "--gpus", "1"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0 and "PREFLIGHT OK" in res.stdout and res.stdout.count("PASS  ") == 4, res.stdout[-3000:]
