@@ -179,9 +179,17 @@ def test_blocksolve_full_shape_ml20m_1000_iterations_within_1e4_of_oracle():
     model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
     model.sgd(cu.DeviceCSR(tr), HYPER, 42, 0, iters, mode="blocksolve")
     got = model.loss(cu.DeviceCSR(te))
+    # (the two oracle runs -- 1.4e8 sequential updates each, ~45 s of one host core -- side by side: ctypes calls release the GIL)
+    import threading
+    states = {order: orc.init_model(tr.rows, tr.cols, f) for order in (orc.DOT_TREE16, orc.DOT_SEQ)}
+    runs = [threading.Thread(target=orc.sgd_iterations, args=(_as_orc(tr),) + tuple(states[order]) + (tr.global_bias, HYPER, 42, 0, iters),
+                             kwargs={"dot_order": order}) for order in states]
+    for t in runs:
+        t.start()
+    for t in runs:
+        t.join()
     for order in (orc.DOT_TREE16, orc.DOT_SEQ):
-        P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
-        orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, iters, dot_order=order)
+        P, Q, ub, ib = states[order]
         want = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias, dot_order=order)
         assert abs(got["rmse"] - want["rmse"]) <= 1e-4, (order, got["rmse"], want["rmse"])
         assert abs(got["mae"] - want["mae"]) <= 1e-4, order
