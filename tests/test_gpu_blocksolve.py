@@ -179,15 +179,10 @@ def test_blocksolve_full_shape_ml20m_1000_iterations_within_1e4_of_oracle():
     model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
     model.sgd(cu.DeviceCSR(tr), HYPER, 42, 0, iters, mode="blocksolve")
     got = model.loss(cu.DeviceCSR(te))
-    # (the two oracle runs -- 1.4e8 sequential updates each, ~45 s of one host core -- side by side: ctypes calls release the GIL)
-    import threading
-    states = {order: orc.init_model(tr.rows, tr.cols, f) for order in (orc.DOT_TREE16, orc.DOT_SEQ)}
-    runs = [threading.Thread(target=orc.sgd_iterations, args=(_as_orc(tr),) + tuple(states[order]) + (tr.global_bias, HYPER, 42, 0, iters),
-                             kwargs={"dot_order": order}) for order in states]
-    for t in runs:
-        t.start()
-    for t in runs:
-        t.join()
+    # (the two oracle runs -- 1.4e8 sequential updates each, ~45 s of one host core -- were started at collection time and ran beside
+    # the GPU tests in front of this one: tests/conftest.py)
+    import conftest
+    states = {orc.DOT_TREE16: conftest.oracle_state("ml-20m", f, iters, "TREE16"), orc.DOT_SEQ: conftest.oracle_state("ml-20m", f, iters, "SEQ")}
     for order in (orc.DOT_TREE16, orc.DOT_SEQ):
         P, Q, ub, ib = states[order]
         want = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias, dot_order=order)
@@ -235,8 +230,8 @@ def test_blocksolve_full_shape_netflix_f128_against_the_cpu_oracle():
     assert d_tr.blocksolve_items() > 0, "no item above the threshold: this would test the ordered walk"
     model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
     model.sgd(d_tr, HYPER, 42, 0, iters, mode="blocksolve")
-    P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
-    orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, iters, dot_order=orc.DOT_TREE16)
+    import conftest
+    P, Q, ub, ib = conftest.oracle_state("netflix", f, iters, "TREE16")  # (started at collection time: tests/conftest.py)
     diffs = _max_diffs(model, (P, Q, ub, ib))
     assert max(diffs) <= 5e-6, diffs
     got = model.loss(cu.DeviceCSR(te))
