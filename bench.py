@@ -50,7 +50,8 @@ def load_dataset(name, seed, rank, barrier):
     path = os.path.join(tempfile.gettempdir(), "cu2rec_synth_%s_%d.npz" % (name, seed))
     if rank == 0 and not os.path.exists(path):
         tr, te = synth.make_named(name, seed=seed)
-        tmp = path + ".tmp.npz"
+        import threading
+        tmp = path + ".%d.%d.tmp.npz" % (os.getpid(), threading.get_ident())  # (several processes / threads may find the cache empty at once)
         np.savez(tmp, tr_indptr=tr.indptr, tr_indices=tr.indices, tr_data=tr.data, te_indptr=te.indptr,
                  te_indices=te.indices, te_data=te.data, shape=np.array([tr.rows, tr.cols]),
                  gb=np.array([tr.global_bias], np.float32))

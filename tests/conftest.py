@@ -36,10 +36,14 @@ _FULL_SHAPE_ORACLE_RUNS = {
 }
 
 
+_DATASET_LOCK = __import__("threading").Lock()
+
+
 def _oracle_job(workload, f, iters, order_name):
     import bench
     from oracle import oracle as orc
-    tr, _ = bench.load_dataset(workload, 20240917, 0, lambda: None)
+    with _DATASET_LOCK:  # (one generation of a missing set, not one per job)
+        tr, _ = bench.load_dataset(workload, 20240917, 0, lambda: None)
     state = orc.init_model(tr.rows, tr.cols, f)
     orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias), *state, tr.global_bias,
                        (0.01, 0.02, 0.02, 0.02, 0.02), 42, 0, iters, dot_order=getattr(orc, "DOT_" + order_name))
