@@ -50,6 +50,13 @@ def _oracle_job(workload, f, iters, order_name):
     return state
 
 
+def pytest_collection_modifyitems(config, items):
+    # the tests that join the background oracle runs go LAST: the runs then have the whole session to finish in
+    late = [it for it in items if any(name in it.nodeid for name in _FULL_SHAPE_ORACLE_RUNS)]
+    if late:
+        items[:] = [it for it in items if it not in late] + late
+
+
 def pytest_collection_finish(session):
     from concurrent.futures import ThreadPoolExecutor
     wanted = [(name, spec) for name, spec in _FULL_SHAPE_ORACLE_RUNS.items() if any(name in item.nodeid for item in session.items)]
