@@ -147,15 +147,20 @@ def cpu_baseline(train, test, f, hyper, budget_s=12.0):
     return out
 
 
-# A user-sharded run is NOT the sequential run (the item side is reconciled once per period): what its test RMSE may differ by from
-# the N = 1 (= mf_sequential.cu) result, per N -- measured by emulation on one GPU and pinned by tests/test_gpu_sharded.py
-# (DESIGN.md section 7).  Only N <= 2 is inside the north star's 1e-4.
+# A user-sharded run is NOT the sequential run (the item side is reconciled once per period): what its test RMSE differs by from the
+# N = 1 (= mf_sequential.cu) result, per N -- measured with the PRODUCT's driver at full size (N ranks as threads of one process on one
+# GPU) and pinned by tests/test_gpu_sharded.py (profiles/r05_sharded_converged.txt).
 SHARDED_TOLERANCE = {
-    "against": "test RMSE of the N = 1 run (= the sequential result) at equal iterations, `adaptive` merge, one exchange per epoch",
-    "ml-20m f=100, 1,000 iterations": {"2": {"measured": -1e-5, "accepted": 1e-4}, "4": {"measured": 1.7e-4, "accepted": 3e-4},
-                                       "8": {"measured": 3.9e-4, "accepted": 6e-4}},
-    "netflix f=128, 660 iterations": {"8": {"measured": -1.2e-3, "accepted": 1.6e-3}},
-    "north_star_bar": 1e-4, "meets_north_star_bar": "N <= 2 only"}
+    "against": "test RMSE of the N = 1 run (= the sequential result), block-solve per shard, `adaptive` merge, one exchange per epoch",
+    "fixed iterations at lr .01": {
+        "ml-20m f=100, 1,000 iterations": {"2": {"measured": -1e-5, "accepted": 1e-4}, "4": {"measured": 1.7e-4, "accepted": 3e-4},
+                                           "8": {"measured": 3.9e-4, "accepted": 6e-4}},
+        "netflix f=128, 660 iterations": {"8": {"measured": -1.2e-3, "accepted": 1.6e-3}}},
+    "converged (reference LR schedule, 8,000 iterations): [end point, best checkpoint]": {
+        "ml-20m f=100": {"2": [-4.3e-3, -4.3e-5], "4": [-3.5e-3, -2.6e-4], "8": [-7.7e-3, -2.7e-4]},
+        "netflix f=128": {"8": [-5.0e-3, 1.8e-3]}},
+    "north_star_bar": 1e-4, "meets_north_star_bar": "N <= 2 only (fixed iterations)",
+    "survey_8e_bar": "converged <= 1e-3 of N = 1: met at the best checkpoint on the ML-20M shape, not at the schedule's end point, not on the Netflix shape"}
 
 # rocprofv3 --pmc summaries (tools/pmc_summary.py) of THIS workload and mode, if one is committed: (workload, factors, mode) -> file
 def _latest(pattern):
