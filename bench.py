@@ -170,10 +170,10 @@ def _latest(pattern):
     return os.path.relpath(found[-1], ROOT) if found else None
 
 
-PMC_PROFILES = {("ml-20m", 100, "blocksolve"): _latest("r0?_pmc_blocksolve_ml20m_f100.json"),
-                ("netflix", 128, "blocksolve"): _latest("r0?_pmc_blocksolve_netflix_f128.json")}
-KERNEL_STATS = {("ml-20m", 100, "blocksolve"): _latest("r0?_kernel_stats_blocksolve_ml20m_f100.csv"),
-                ("netflix", 128, "blocksolve"): _latest("r0?_kernel_stats_blocksolve_netflix_f128.csv")}
+PMC_PROFILES = {("ml-20m", 100, "blocksolve"): _latest("r[0-9][0-9]_pmc_blocksolve_ml20m_f100.json"),
+                ("netflix", 128, "blocksolve"): _latest("r[0-9][0-9]_pmc_blocksolve_netflix_f128.json")}
+KERNEL_STATS = {("ml-20m", 100, "blocksolve"): _latest("r[0-9][0-9]_kernel_stats_blocksolve_ml20m_f100.csv"),
+                ("netflix", 128, "blocksolve"): _latest("r[0-9][0-9]_kernel_stats_blocksolve_netflix_f128.csv")}
 # the kernels of one SGD iteration of a mode (the schedule kernels run once per batch of 64 iterations: counted per iteration below)
 ITERATION_KERNELS = {"blocksolve": ("bs_gram_kernel", "bs_solve_kernel", "bs_update_kernel", "sgd_ordered_kernel")}
 
@@ -382,54 +382,85 @@ def main():
     rmse0 = job.loss(d_test)["rmse"]
     log("initial test rmse %.6f" % rmse0)
 
+    def reduce_max(values):
+        """Element-wise MAX over the ranks of a list of floats (outside every clock)."""
+        if world == 1:
+            return [float(v) for v in values]
+        t = torch.tensor(list(values), dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.cpu().tolist()]
+
+    def warm_up(j, m):
+        """W untimed steps.  With several ranks the warm-up also carries TWO full-size exchanges (the wire buffer is always the whole
+        item side: RCCL sets up its channels for that message size on the first, the second runs in the steady state) and leaves
+        the cadence at zero, so that no timed region holds the communicator's first large collective."""
+        if world > 1 and args.warmup >= 2:
+            j.run(hyper, 42, 0, args.warmup - 1, m)
+            j.exchange()
+            j.run(hyper, 42, args.warmup - 1, 1, m)
+            j.exchange()
+        else:
+            j.run(hyper, 42, 0, args.warmup, m)
+            if world > 1:
+                j.exchange()
+        torch.cuda.synchronize()
+        check(L.cu2rec_check_faults())
+
     it = 0
-    job.run(hyper, 42, it, args.warmup, mode)
-    torch.cuda.synchronize()
-    check(L.cu2rec_check_faults())
+    warm_up(job, mode)
     it += args.warmup
-    log("warmup done")
+    warm_exchanges = job.info()["exchanges"]
+    log("warmup done (%d exchange(s) inside it)" % warm_exchanges)
     ev = HipEvents()
     e0, e1 = ev.new(), ev.new()
 
-    def timed_region(start_it):
+    def timed_region(j, m, start_it):
+        """EXACTLY K steps between barrier + device synchronisation on both sides.  The wall clock stops after THIS rank's
+        synchronisation -- the trailing barrier is outside it -- and the MAX over ranks of every region is taken afterwards,
+        outside every clock (reduce_max)."""
         barrier()
         torch.cuda.synchronize()
+        x0 = j.info()["exchanges"]
         t0 = time.perf_counter()
         ev.record(e0)
-        job.run(hyper, 42, start_it, args.steps, mode)
+        j.run(hyper, 42, start_it, args.steps, m)
         ev.record(e1)
         torch.cuda.synchronize()
-        barrier()
         dt = time.perf_counter() - t0
-        return dt, 1e-3 * ev.ms(e0, e1)
+        barrier()
+        return dt, 1e-3 * ev.ms(e0, e1), j.info()["exchanges"] - x0
 
-    regions = []
-    first, first_dev = timed_region(it)
+    regions = [timed_region(job, mode, it)]
     it += args.steps
-    regions.append((first, first_dev))
     # A short region is mostly launch + synchronisation noise: every region is EXACTLY K steps, and regions are repeated until
     # a quarter of a second has been timed in all (at least 5 when one region is shorter than that, at most 400).  Reported: ALL
     # timed steps over ALL timed seconds, i.e. the MEAN region -- calls of K steps run out of schedule windows of 64 iterations
-    # (ordered.hip), so one region in three carries the next window's schedule kernels and the others none: the median region
-    # (on the line as timed_region_s_median) would pick the cheap ones.
-    first_all = first
-    if world > 1:  # every rank must take the same decision: the regions are bracketed by barriers
-        t = torch.tensor([first], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        first_all = float(t.item())
+    # (ordered.hip), so one region in three carries the next window's schedule kernels and the others none, and with several ranks
+    # one region in sync_every / K carries an exchange: the median region (on the line as timed_region_s_median) would pick the
+    # cheap ones.
+    first_all = reduce_max([regions[0][0]])[0]  # every rank must take the same decision: the regions are bracketed by barriers
     n_regions = 1 if first_all >= MIN_TIMED_S else int(min(400, max(5, np.ceil(MIN_TIMED_S / max(first_all, 1e-6)))))
+    if world > 1:  # (whole exchange periods: the mean region then carries the exchanges' true share)
+        per_period = int(np.ceil(info["sync_every"] / max(args.steps, 1)))
+        n_regions = int(min(400, max(n_regions, per_period) if per_period <= 400 else n_regions))
     for _ in range(n_regions - 1):
-        regions.append(timed_region(it))
+        regions.append(timed_region(job, mode, it))
         it += args.steps
     check(L.cu2rec_check_faults())
-    elapsed = float(np.mean([r[0] for r in regions]))
+    wall_all = reduce_max([r[0] for r in regions])  # per region: the slowest rank's wall time
+    elapsed = float(np.mean(wall_all))
     elapsed_dev = float(np.mean([r[1] for r in regions]))
-    elapsed_median = float(np.median([r[0] for r in regions]))
+    elapsed_median = float(np.median(wall_all))
+    regions_with_exchange = int(sum(1 for r in regions if r[2] > 0))
+    log("timed: %d region(s) of %d steps, mean %.6f s (device %.6f s), median %.6f s, %d with an exchange"
+        % (len(regions), args.steps, elapsed, elapsed_dev, elapsed_median, regions_with_exchange))
+    x_stats = job.exchange_stats()  # (every stream is synchronised here: every exchange's event pair has completed)
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    log("timed: %d region(s) of %d steps, mean %.6f s (device %.6f s), median %.6f s" % (len(regions), args.steps, elapsed, elapsed_dev, elapsed_median))
+        mine = {"rank": rank, "device_seconds_mean_region": elapsed_dev, "wall_seconds_mean_region": float(np.mean([r[0] for r in regions])),
+                "users": users_active, "exchange_seconds_mean": x_stats["mean_seconds"], "comm": comm.info()}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     job.exchange()
     final = job.loss(d_test)
     final_iterations = it
@@ -447,23 +478,13 @@ def main():
         # barrier-bracketed regions (n_regions was agreed on above), so the ranks stay in lockstep.
         hog_model = fresh_model()
         hog_job = sharded.ShardJob(comm, hog_model, d_train, user_offset=user_offset, sync_every=args.sync_every, merge=args.merge)
-        hog_job.run(hyper, 42, 0, args.warmup, "hogwild")
-        torch.cuda.synchronize()
+        warm_up(hog_job, "hogwild")
         hit, hregs = args.warmup, []
         for _ in range(n_regions):
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            hog_job.run(hyper, 42, hit, args.steps, "hogwild")
-            torch.cuda.synchronize()
-            barrier()
-            hregs.append(time.perf_counter() - t0)
+            hregs.append(timed_region(hog_job, "hogwild", hit)[0])
             hit += args.steps
         check(L.cu2rec_check_faults())
-        h_el = float(np.median(hregs))
-        t = torch.tensor([h_el], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        h_el = float(t.item())
+        h_el = float(np.mean(reduce_max(hregs)))  # (the mean region, like the headline: the exchanges' share is in it)
         hog_job.exchange()
         h_final = hog_job.loss(d_test)
         side["hogwild_sharded_mode"] = {
@@ -606,9 +627,18 @@ def main():
                        "mode": mode, "updates_per_step": total_users, "updates_per_step_this_rank": users_active,
                        "sync_every": info["sync_every"] if world > 1 else None, "merge": args.merge if world > 1 else None,
                        "exchanges": exchanges, "wire_bytes_per_exchange": info["wire_bytes"] if world > 1 else None,
+                       "exchanges_in_warmup": warm_exchanges,
                        "sharded_run_tolerance": SHARDED_TOLERANCE if world > 1 else None},
             "timed_region_s": elapsed, "timed_region_s_mean": elapsed, "timed_region_s_median": elapsed_median, "timed_regions": len(regions),
-            "timed_region_s_min_max": [round(min(r[0] for r in regions), 6), round(max(r[0] for r in regions), 6)],
+            "timed_region_s_min_max": [round(min(wall_all), 6), round(max(wall_all), 6)],
+            "timed_region_clock": "per region: barrier, device synchronisation, clock starts, K steps, device synchronisation, clock STOPS, barrier; "
+                                  "per region the MAX over ranks, reduced after the last region; value = all timed steps / the sum of those maxima",
+            "timed_regions_with_exchange": regions_with_exchange,
+            "exchange": None if world == 1 else {
+                "timed": x_stats["timed"], "mean_seconds": x_stats["mean_seconds"], "max_seconds": x_stats["max_seconds"],
+                "what": "items_wire_pack -> all-reduce of wire_bytes_per_exchange -> items_wire_apply, HIP events on the exchange's stream, rank 0 "
+                        "(includes the wait for the slowest rank); warm-up exchanges included in the count"},
+            "rccl": comm.info(), "per_rank": per_rank,
             "test_rmse": final["rmse"], "test_rmse_initial": rmse0, "iterations_run": final_iterations,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_over_algorithmic": (traffic / (users_active * bytes_per_update)) if traffic else None,

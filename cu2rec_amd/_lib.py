@@ -45,6 +45,12 @@ class TrainStats(C.Structure):
                 ("last_test_mae", C.c_float), ("last_test_rmse", C.c_float)]
 
 
+class CommInfo(C.Structure):
+    """cu2rec_comm_info_t: what RCCL itself reports about the attached communicator."""
+    _fields_ = [("rank", C.c_int), ("nranks", C.c_int), ("rccl_nranks", C.c_int), ("rccl_rank", C.c_int), ("rccl_device", C.c_int),
+                ("rccl_version", C.c_int), ("is_callback", C.c_int)]
+
+
 _P = C.c_void_p
 _ip, _fp, _dp = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)
 
@@ -124,12 +130,14 @@ SIGNATURES = {
     "cu2rec_comm_from_nccl": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "cu2rec_comm_from_callback": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "cu2rec_comm_destroy": (None, [_P]),
+    "cu2rec_comm_info": (C.c_int, [_P, C.POINTER(CommInfo)]),
     "cu2rec_shard_job_create": (C.c_int, [_P, _P, _P, C.c_int, _P, C.POINTER(_P)]),
     "cu2rec_shard_job_destroy": (None, [_P]),
     "cu2rec_shard_job_run": (C.c_int, [_P, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int]),
     "cu2rec_shard_job_exchange": (C.c_int, [_P]),
     "cu2rec_shard_job_loss": (C.c_int, [_P, _P, _dp, _dp, _dp, _fp, _fp]),
     "cu2rec_shard_job_info": (C.c_int, [_P, _ip, _ip, _dp, _dp, C.POINTER(C.c_size_t)]),
+    "cu2rec_shard_job_exchange_stats": (C.c_int, [_P, _ip, _dp, _dp]),
     "cu2rec_train_sharded": (C.c_int, [_P, _P, C.POINTER(Config), C.c_int, C.c_int, _P, C.POINTER(TrainStats)]),
     "cu2rec_csr_slice": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _ip, _ip]),
     "cu2rec_items_delta_pack": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P]),

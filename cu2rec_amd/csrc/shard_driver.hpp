@@ -8,7 +8,8 @@
 //     the world-2 gloo tests of tests/test_parallel_cpu.py run this code -- the product's exchange logic, not a restatement of
 //     it -- on a box without a GPU.  Test infrastructure: never linked into the library.
 // Backend B provides:
-//   types     Model, Csr, Comm, Stream, Buffer<T> (allocate(n), ptr, upload(host, n), download(host, n)), Clock (train())
+//   types     Model, Csr, Comm, Stream, Buffer<T> (allocate(n), ptr, upload(host, n), download(host, n)), Clock (train(); the
+//             exchanges' timers: start(stream), stop(stream), done(), elapsed_ms())
 //   shape     rows(m), cols(m), n_factors(m), ldq(m), Q(m), item_bias(m); csr_rows(c), csr_nnz(c), csr_max_item(c),
 //             csr_users_with_ratings(c), csr_structure(c, indptr, indices)
 //   memory    copy(dst, src, n) inside the backend's memory; to_backend(dst, src, bytes, stream), to_host(dst, src, bytes, stream)
@@ -21,6 +22,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "common.hpp"
@@ -48,6 +50,13 @@ struct ShardDriver {
     double users_total = 0, nnz_total = 0;
     Buffer<float> Q_base, ib_base, wire, weight;
     Buffer<double> sums;  // 3 doubles for the loss reduction
+    // device time of the exchanges (cu2rec_shard_job_exchange_stats): a ring of event pairs, read when their slot comes round
+    // again or when the statistics are asked for -- never a wait inside the data path
+    static constexpr int kTimers = 32;
+    std::vector<std::unique_ptr<typename B::Clock>> timers;
+    std::vector<char> timer_pending;
+    int exchanges_timed = 0;
+    double exchange_seconds = 0, exchange_seconds_max = 0;
 
     // One rank's share of a sharded run: its users' CSR slice and model slice (P, user_bias for the local users; Q and
     // item_bias replicated), the snapshot the item deltas are taken against, the wire buffer.
@@ -128,12 +137,41 @@ struct ShardDriver {
     void exchange(Stream stream) {
         since_sync = 0;
         if (comm.nranks == 1 && !comm.collective()) return;
+        if (timers.empty()) {
+            timers.resize(kTimers);
+            timer_pending.assign(kTimers, 0);
+        }
+        const int slot = exchanges % kTimers;
+        harvest(slot);
+        if (!timers[slot]) timers[slot] = std::make_unique<typename B::Clock>();
+        const bool timed = !timer_pending[slot];  // (still in flight a whole ring later: that old sample is kept, this exchange goes untimed)
+        if (timed) timers[slot]->start(stream);
         B::wire_pack(B::Q(model), B::item_bias(model), Q_base.ptr, ib_base.ptr, weight.ptr, B::cols(model), B::n_factors(model), B::ldq(model),
                      wire.ptr, stream);
         comm.allreduce(wire.ptr, wire_floats(), false, stream);
         B::wire_apply(B::Q(model), B::item_bias(model), Q_base.ptr, ib_base.ptr, B::cols(model), B::n_factors(model), B::ldq(model), wire.ptr,
                       scale(), stream);
+        if (timed) {
+            timers[slot]->stop(stream);
+            timer_pending[slot] = 1;
+        }
         ++exchanges;
+    }
+
+    void harvest(int slot) {
+        if (!timer_pending[slot] || !timers[slot]->done()) return;
+        const double s = 1e-3 * timers[slot]->elapsed_ms();
+        exchange_seconds += s;
+        exchange_seconds_max = std::max(exchange_seconds_max, s);
+        ++exchanges_timed;
+        timer_pending[slot] = 0;
+    }
+
+    void exchange_stats(int *timed, double *seconds, double *max_seconds) {
+        for (size_t slot = 0; slot < timers.size(); ++slot) harvest(static_cast<int>(slot));
+        if (timed) *timed = exchanges_timed;
+        if (seconds) *seconds = exchange_seconds;
+        if (max_seconds) *max_seconds = exchange_seconds_max;
     }
 
     // n_iters iterations on the local shard, an exchange every sync_every iterations (the cadence runs across calls)

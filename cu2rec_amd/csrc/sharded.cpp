@@ -41,6 +41,9 @@ struct Rccl {
     decltype(&ncclCommAbort) CommAbort = nullptr;                  // optional
     decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;  // optional
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;        // optional (cu2rec_comm_info)
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;  // optional
+    decltype(&ncclCommCuDevice) CommCuDevice = nullptr;  // optional
     int version = 0;
     bool ok = false;
     std::string why;
@@ -73,6 +76,9 @@ Rccl &rccl() {
         r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
         r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(sym("ncclCommGetAsyncError"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+        r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(sym("ncclCommCuDevice"));
         if (!(r.GetVersion && r.GetUniqueId && r.CommInitRank && r.AllReduce && r.CommDestroy)) {
             r.why = "librccl lacks ncclGetVersion / ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
             return;
@@ -214,6 +220,19 @@ Comm *comm_adopt_rccl(void *nccl_comm, int rank, int nranks) {
     return c;
 }
 
+// What RCCL itself says about the attached communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): the proof on a
+// bench line that the collective spans N ranks, not what the caller asked for
+void comm_info(const Comm &c, cu2rec_comm_info_t &out) {
+    out = cu2rec_comm_info_t{c.rank, c.nranks, 0, -1, -1, 0, c.fn != nullptr ? 1 : 0};
+    if (!c.nccl) return;
+    Rccl &r = rccl();
+    out.rccl_version = r.version;
+    const ncclComm_t comm = static_cast<ncclComm_t>(c.nccl);
+    if (r.CommCount) rccl_check(r.CommCount(comm, &out.rccl_nranks), "ncclCommCount");
+    if (r.CommUserRank) rccl_check(r.CommUserRank(comm, &out.rccl_rank), "ncclCommUserRank");
+    if (r.CommCuDevice) rccl_check(r.CommCuDevice(comm, &out.rccl_device), "ncclCommCuDevice");
+}
+
 Comm *comm_from_callback(cu2rec_allreduce_fn fn, void *ctx, int rank, int nranks) {
     require(nranks >= 1 && rank >= 0 && rank < nranks && (fn || nranks == 1), "cu2rec_comm_from_callback: bad argument");
     Comm *c = new Comm;
@@ -288,6 +307,13 @@ int cu2rec_comm_from_callback(cu2rec_allreduce_fn fn, void *ctx, int rank, int n
     });
 }
 
+int cu2rec_comm_info(const cu2rec_comm *c, cu2rec_comm_info_t *out) {
+    return guarded([&] {
+        require(c && c->impl && out, "cu2rec_comm_info: null argument");
+        comm_info(*c->impl, *out);
+    });
+}
+
 void cu2rec_comm_destroy(cu2rec_comm *c) {
     if (!c) return;
     delete c->impl;
@@ -339,6 +365,13 @@ int cu2rec_shard_job_info(const cu2rec_shard_job *job, int *sync_every, int *exc
         if (users_total) *users_total = job->impl.users_total;
         if (nnz_total) *nnz_total = job->impl.nnz_total;
         if (wire_bytes) *wire_bytes = job->impl.wire_floats() * sizeof(float);
+    });
+}
+
+int cu2rec_shard_job_exchange_stats(cu2rec_shard_job *job, int *timed, double *seconds, double *max_seconds) {
+    return guarded([&] {
+        require(job, "cu2rec_shard_job_exchange_stats: null argument");
+        job->impl.exchange_stats(timed, seconds, max_seconds);
     });
 }
 

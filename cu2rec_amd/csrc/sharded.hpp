@@ -35,6 +35,7 @@ void comm_unique_id(void *id_out128);
 Comm *comm_create_rccl(const void *id128, int rank, int nranks);
 Comm *comm_adopt_rccl(void *nccl_comm, int rank, int nranks);
 Comm *comm_from_callback(cu2rec_allreduce_fn fn, void *ctx, int rank, int nranks);
+void comm_info(const Comm &c, cu2rec_comm_info_t &out);
 
 // The backend of the driver template (shard_driver.hpp) in the product: device memory, the HIP kernels, RCCL.
 struct HipBackend {

@@ -26,6 +26,12 @@ struct HipClock {  // the SGD stretch between two loss checks, by events on the 
         CU2REC_HIP(hipEventElapsedTime(&ms, ev_start, ev_stop));
         return ms;
     }
+    bool done() {  // has everything up to stop() finished?  (the sharded driver's exchange timers: read without waiting)
+        const hipError_t q = hipEventQuery(ev_stop);
+        if (q == hipErrorNotReady) return false;
+        CU2REC_HIP(q);
+        return true;
+    }
     void drain() { CU2REC_HIP(hipDeviceSynchronize()); }
 };
 

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from . import api
-from ._lib import Config, Hyper, TrainStats, check, lib
+from ._lib import CommInfo, Config, Hyper, TrainStats, check, lib
 
 MERGES = {"mean": 0, "weighted": 1, "sum": 2, "adaptive": 3}
 
@@ -43,6 +43,13 @@ class Comm:
             got = share(bytes(uid) if self.rank == 0 else None)
             uid = (C.c_ubyte * 128).from_buffer_copy(got)
         check(lib().cu2rec_comm_create(uid, self.rank, self.nranks, C.byref(self._h)))
+
+    def info(self):
+        """cu2rec_comm_info: rank / nranks as created, and what RCCL reports (ncclCommCount, ncclCommUserRank, ncclCommCuDevice,
+        ncclGetVersion) -- rccl_nranks 0 without an RCCL communicator (one rank, or the callback form)."""
+        ci = CommInfo()
+        check(lib().cu2rec_comm_info(self._h, C.byref(ci)))
+        return {name: int(getattr(ci, name)) for name, _ in CommInfo._fields_}
 
     def close(self):
         if self._h:
@@ -98,6 +105,12 @@ class ShardJob:
         check(lib().cu2rec_shard_job_info(self._h, C.byref(se), C.byref(ex), C.byref(ut), C.byref(nt), C.byref(wb)))
         return {"sync_every": se.value, "exchanges": ex.value, "users_total": ut.value, "nnz_total": nt.value,
                 "wire_bytes": wb.value}
+
+    def exchange_stats(self):
+        """cu2rec_shard_job_exchange_stats: device time of the exchanges whose event pairs have completed (synchronise first)."""
+        n, s, m = C.c_int(), C.c_double(), C.c_double()
+        check(lib().cu2rec_shard_job_exchange_stats(self._h, C.byref(n), C.byref(s), C.byref(m)))
+        return {"timed": n.value, "seconds": s.value, "max_seconds": m.value, "mean_seconds": (s.value / n.value) if n.value else None}
 
     def train(self, test, cfg, mode=api.SGD_HOGWILD, verbose=True):
         """cu2rec_train_sharded -> (losses, stats); cfg.learning_rate / cur_iterations updated like the reference's."""

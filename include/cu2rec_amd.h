@@ -452,6 +452,17 @@ int cu2rec_comm_create(const void *unique_id, int rank, int nranks, cu2rec_comm 
 int cu2rec_comm_from_nccl(void *nccl_comm, int rank, int nranks, cu2rec_comm **out);    /* not owned */
 int cu2rec_comm_from_callback(cu2rec_allreduce_fn fn, void *ctx, int rank, int nranks, cu2rec_comm **out);
 void cu2rec_comm_destroy(cu2rec_comm *comm);
+/* What the communicator really is, for a bench line / a preflight to PROVE the collective's world: rank / nranks as given at
+ * creation; rccl_nranks / rccl_rank / rccl_device from ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the attached
+ * ncclComm_t (all 0 / -1 / -1 when no RCCL communicator is attached: one rank, or the callback form); rccl_version from
+ * ncclGetVersion (0 if RCCL was never loaded).  Any pointer may be NULL. */
+typedef struct cu2rec_comm_info_t {
+    int rank, nranks;
+    int rccl_nranks, rccl_rank, rccl_device;
+    int rccl_version;
+    int is_callback; /* 1: the caller's all-reduce (tests), no RCCL on the data path */
+} cu2rec_comm_info_t;
+int cu2rec_comm_info(const cu2rec_comm *comm, cu2rec_comm_info_t *out);
 
 typedef enum cu2rec_merge {
     CU2REC_MERGE_MEAN = 0,     /* scale 1 / nranks */
@@ -483,6 +494,11 @@ int cu2rec_shard_job_loss(cu2rec_shard_job *job, const cu2rec_csr *ratings, doub
                           double *n_total, float *mae, float *rmse);
 int cu2rec_shard_job_info(const cu2rec_shard_job *job, int *sync_every, int *exchanges, double *users_total,
                           double *nnz_total, size_t *wire_bytes);
+/* Device time of the exchanges so far: every exchange (items_wire_pack -> all-reduce -> items_wire_apply) is bracketed by a pair
+ * of events on its stream; `timed` of them have completed and been read (an exchange whose events were still in flight when
+ * their slot was needed again is not counted), `seconds` is their sum on THIS rank -- it includes the wait for the slowest
+ * peer.  Call after the stream has been synchronised to have every exchange counted.  Pointers may be NULL. */
+int cu2rec_shard_job_exchange_stats(cu2rec_shard_job *job, int *timed, double *seconds, double *max_seconds);
 /* cu2rec_train over all ranks: same schedule, same stdout lines (rank 0 prints), patience / learning-rate decay on the
  * GLOBAL test RMSE; `test` is the rank's slice of the test set; stats->updates counts the whole population. */
 int cu2rec_train_sharded(cu2rec_shard_job *job, const cu2rec_csr *test, cu2rec_config *cfg, int mode, int verbose,

@@ -66,6 +66,7 @@ struct HostClock {
     void start(void *) { t0 = std::chrono::steady_clock::now(); }
     void stop(void *) { t1 = std::chrono::steady_clock::now(); }
     float elapsed_ms() { return std::chrono::duration<float, std::milli>(t1 - t0).count(); }
+    bool done() { return true; }
     void drain() {}
 };
 
@@ -214,6 +215,10 @@ int host_shard_info(const host_job *j, int *sync_every, int *exchanges, double *
         *users_total = j->drv->users_total;
         *nnz_total = j->drv->nnz_total;
     });
+}
+
+int host_shard_exchange_stats(host_job *j, int *timed, double *seconds, double *max_seconds) {
+    return guarded([&] { j->drv->exchange_stats(timed, seconds, max_seconds); });
 }
 
 int host_shard_train(host_job *j, const int *te_indptr, const int *te_indices, const float *te_data, int te_rows, int te_nnz, cu2rec_config *cfg,

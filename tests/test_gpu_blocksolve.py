@@ -314,6 +314,80 @@ def test_tier2_converged_runs_under_the_reference_schedule_pick_the_headline_mod
     assert 1e-4 < gaps["hogwild-resident"] <= 2e-2 and 1e-4 < gaps["hogwild-streaming"] <= 2e-2, gaps
 
 
+def test_converged_ml20m_blocksolve_against_the_cpu_oracle_in_the_references_own_arithmetic():
+    """The north-star sentence as written, on BASELINE.json configs[2] (ML-20M shape, f=100): "converged P/Q/bias outputs must match
+    mf_sequential.cu on fixed seed within 1e-4 RMSE" -- the product's cu2rec_train in the headline mode (CU2REC_SGD_BLOCKSOLVE) against
+    the CPU ORACLE's train() (orc_train = mf_sequential.cu:102-201 under training.cu:118,146-155's schedule: check every 500, patience
+    2, decay 0.2, lr .01) in the reference's OWN arithmetic: the sequential dot of mf_sequential.cu:122-125 (DOT_SEQ), run once with
+    the float loss accumulators of mf_sequential.cu:147-174 (ACC_F32: what the reference prints and takes its patience decisions on)
+    and once with double ones (ACC_F64: loss.cu:185-190).  5,000 iterations = three decays (lr 8e-5 from 4,500 on): the model has
+    stopped moving.  The oracle runs are 6.9e8 sequential updates each, started at collection time (tests/conftest.py).
+      * the learning rate decays at the SAME iterations in all three runs -- no patience decision flips between the kernels' arithmetic
+        (tree dot, block-wise re-associated sums, fp64 loss sums) and the reference's (sequential dot, float or double sums);
+      * against the ACC_F64 oracle: every logged test RMSE (11 checks) and the final one within 1e-4; train RMSE likewise;
+      * against the ACC_F32 oracle -- the reference's printed numbers: its float accumulators drop the small squared errors once the
+        running sum is large, so what it PRINTS is 1.6e-3 (test) / 1.0e-2 (train) below the true RMSE of its own model (a property of
+        mf_sequential.cu:147-174, pinned here as a finding); the model it converges to is the ACC_F64 run's bit for bit, and the
+        reference's own loss routine (DOT_SEQ, ACC_F32) applied to the PRODUCT's converged P/Q/biases is within 1e-4 of what it
+        prints for its own;
+      * parameters: max |dP|, |dQ|, |d user_bias|, |d item_bias| reported (profiles/r06_converged_vs_cpu_oracle.json) and bounded."""
+    import json
+    import bench
+    import conftest
+    tr, te = bench.load_dataset("ml-20m", 20240917, 0, lambda: None)
+    f, iters = 100, 5000
+    d_tr, d_te = cu.DeviceCSR(tr), cu.DeviceCSR(te)
+    cfg = api.default_config(total_iterations=iters, n_factors=f, learning_rate=0.01, seed=42, P_reg=0.02, Q_reg=0.02, user_bias_reg=0.02,
+                             item_bias_reg=0.02)
+    P, Q, losses, ub, ib, stats = api.train(d_tr, d_te, cfg, mode="blocksolve", verbose=False, return_stats=True)
+    checks = [(i + 1, float(v)) for i, v in enumerate(losses) if np.isfinite(v)]
+    rec64, state64 = conftest.oracle_converged_run("ml-20m", f, iters, "SEQ", "F64")
+    rec32, state32 = conftest.oracle_converged_run("ml-20m", f, iters, "SEQ", "F32")
+    # ---- the schedule: same checks, same decay iterations, same final rate
+    lr, decays = np.float32(0.01), []
+    last, patience = np.float32(np.finfo(np.float32).max), int(cfg.patience)
+    for it, r in checks:  # (training.cu:129,146-155 replayed on the product's logged losses)
+        if last < np.float32(r):
+            patience -= 1
+        if patience <= 0:
+            patience, lr = int(cfg.patience), np.float32(lr * np.float32(cfg.learning_rate_decay))
+            decays.append(it)
+        last = np.float32(r)
+    assert [c[0] for c in checks] == [e["iteration"] for e in rec64["checks"]] == [e["iteration"] for e in rec32["checks"]]
+    assert decays == rec64["decay_iterations"] == rec32["decay_iterations"] and len(decays) >= 3, (decays, rec64["decay_iterations"], rec32["decay_iterations"])
+    assert float(cfg.learning_rate) == rec64["final_learning_rate"] == rec32["final_learning_rate"] < 1e-4
+    # ---- double accumulators: every logged test RMSE within 1e-4
+    gaps = [abs(r - e["test_rmse"]) for (_, r), e in zip(checks, rec64["checks"])]
+    assert max(gaps) <= 1e-4, list(zip([c[0] for c in checks], gaps))
+    assert abs(checks[-1][1] - rec64["final_test_rmse"]) <= 1e-4
+    assert abs(float(stats.last_train_rmse) - rec64["final_train_rmse"]) <= 1e-4
+    # ---- float accumulators (what the reference binary prints): same model as the F64 run; its own loss routine on OUR factors
+    for a, b in zip(state32, state64):
+        np.testing.assert_array_equal(a, b)
+    ref_on_ours = orc.loss(_as_orc(te), P, Q, ub, ib, tr.global_bias, dot_order=orc.DOT_SEQ, acc=orc.ACC_F32)
+    assert abs(ref_on_ours["rmse"] - rec32["final_test_rmse"]) <= 1e-4, (ref_on_ours["rmse"], rec32["final_test_rmse"])
+    printed_bias = rec64["final_test_rmse"] - rec32["final_test_rmse"]
+    assert 5e-4 <= printed_bias <= 4e-3, printed_bias  # the finding: float sums under-report by ~1.6e-3 on 3.9 M test ratings
+    # ---- parameters
+    names = ("max_abs_dP", "max_abs_dQ", "max_abs_d_user_bias", "max_abs_d_item_bias")
+    diffs = {n: float(np.abs(g.astype(np.float64) - w).max()) for n, g, w in zip(names, (P, Q, ub, ib), state64)}
+    rms = {n.replace("max_abs", "rms"): float(np.sqrt(np.mean((g.astype(np.float64) - w) ** 2))) for n, g, w in zip(names, (P, Q, ub, ib), state64)}
+    assert max(diffs.values()) <= 2e-2 and max(rms.values()) <= 1e-3, (diffs, rms)
+    out = {"what": "cu2rec_train(CU2REC_SGD_BLOCKSOLVE) on one MI355X against oracle/cu2rec_oracle.c orc_train (DOT_SEQ) on one host core; "
+                   "ml-20m shape f=100, 5000 iterations, reference schedule, seed 42",
+           "product": {"checks": checks, "decay_iterations": decays, "final_learning_rate": float(cfg.learning_rate),
+                       "final_test_rmse": checks[-1][1], "final_train_rmse": float(stats.last_train_rmse), "seconds_sgd": float(stats.seconds_sgd)},
+           "cpu_oracle_f64": {k: rec64[k] for k in ("checks", "decay_iterations", "final_learning_rate", "final_test_rmse", "final_train_rmse", "seconds_wall")},
+           "cpu_oracle_f32": {k: rec32[k] for k in ("checks", "decay_iterations", "final_learning_rate", "final_test_rmse", "final_train_rmse", "seconds_wall")},
+           "max_gap_logged_test_rmse_vs_f64": max(gaps), "gap_final_test_rmse_vs_f64": abs(checks[-1][1] - rec64["final_test_rmse"]),
+           "reference_loss_routine_on_product_factors": ref_on_ours["rmse"],
+           "gap_reference_loss_routine_on_product_factors_vs_its_own": abs(ref_on_ours["rmse"] - rec32["final_test_rmse"]),
+           "float_accumulator_bias_of_the_printed_test_rmse": printed_bias, "same_decay_iterations": True, **diffs, **rms}
+    os.makedirs(os.path.join(conftest.ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(conftest.ROOT, "gpurun_out", "converged_vs_cpu_oracle.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+
+
 def test_bin_mf_blocksolve_mode_against_the_oracle_run(tmp_path):
     """bin/mf -m blocksolve end to end (mf.cu:16-99): the printed TEST RMSE lines and the written factors against the
     oracle's sequential run of the same schedule (CU2REC_BLOCKSOLVE_RATE makes half of the items hot on this small set)."""

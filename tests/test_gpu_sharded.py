@@ -395,6 +395,14 @@ def test_bench_self_launches_its_ranks(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["value"] > 0
     assert line["config"]["sharded_run_tolerance"] is not None
+    # the N > 1 region discipline: full-size exchanges in the warm-up, the trailing barrier outside the clock with
+    # the per-region MAX over ranks taken afterwards, the communicator's own account of itself, one record per rank
+    assert line["config"]["exchanges_in_warmup"] == 2
+    assert "clock STOPS, barrier" in line["timed_region_clock"]
+    assert line["timed_regions_with_exchange"] >= 1 and line["exchange"]["timed"] >= 3 and line["exchange"]["mean_seconds"] > 0
+    assert line["rccl"] == {"rank": 0, "nranks": 2, "rccl_nranks": 0, "rccl_rank": -1, "rccl_device": -1, "rccl_version": 0, "is_callback": 1}
+    assert [r["rank"] for r in line["per_rank"]] == [0, 1] and all(r["device_seconds_mean_region"] > 0 for r in line["per_rank"])
+    assert sum(r["users"] for r in line["per_rank"]) == line["config"]["updates_per_step"]
 
 
 def test_scale_preflight_passes_at_one_rank():
@@ -404,6 +412,25 @@ def test_scale_preflight_passes_at_one_rank():
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_preflight.py"), "--gpus", "1"], env=env, stdout=subprocess.PIPE,
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_preflight.py"), "--gpus", "1", "--bench-args",
+                          "--workload ml-1m --factors 50 --no-cpu-baseline --no-side-modes"], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert res.returncode == 0 and "PREFLIGHT OK" in res.stdout and res.stdout.count("PASS  ") == 4, res.stdout[-3000:]
+    assert res.returncode == 0 and "PREFLIGHT OK" in res.stdout and res.stdout.count("PASS  ") == 5, res.stdout[-3000:]
+    assert "ncclCommCount 1, rank 0" in res.stdout and "PREFLIGHT+BENCH OK" in res.stdout, res.stdout[-3000:]
+
+
+def test_scale_preflight_runs_the_drivers_command_under_its_watchdog():
+    """Step 5 of tools/scale_preflight.py at TWO ranks (sharing this box's one GPU through gloo): exactly the driver's launcher line
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2 --steps 20 --warmup 5`), a fresh child in
+    its own process group, the JSON line checked (n_gpus, per-rank records, an exchange inside a timed region); and the watchdog
+    itself: with a limit far too short the group is killed and the tool leaves non-zero."""
+    import subprocess
+    env = dict(os.environ, CU2REC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    tool = [sys.executable, os.path.join(ROOT, "tools", "scale_preflight.py"), "--gpus", "2", "--bench-only", "--bench-args",
+            "--workload ml-1m --factors 50 --no-cpu-baseline --no-side-modes --sync-every 8"]
+    res = subprocess.run(tool, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 0 and "PREFLIGHT+BENCH OK" in res.stdout and '"n_gpus": 2' in res.stdout, res.stdout[-3000:]
+    res = subprocess.run(tool + ["--bench-timeout", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert res.returncode == 1 and "watchdog" in res.stdout and "PREFLIGHT+BENCH FAILED" in res.stdout, res.stdout[-3000:]

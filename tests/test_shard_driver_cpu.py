@@ -102,6 +102,11 @@ class HostJob:
         self._ck(self.L.host_shard_info(self.h, C.byref(se), C.byref(ex), C.byref(ut), C.byref(nt)))
         return {"sync_every": se.value, "exchanges": ex.value, "users_total": ut.value, "nnz_total": nt.value}
 
+    def exchange_stats(self):
+        n, sec, mx = C.c_int(), C.c_double(), C.c_double()
+        self._ck(self.L.host_shard_exchange_stats(self.h, C.byref(n), C.byref(sec), C.byref(mx)))
+        return {"timed": n.value, "seconds": sec.value, "max_seconds": mx.value}
+
     def train(self, te, u0, u1, cfg, verbose=False):
         ip = masked(te, u0, u1)
         idx, dat = np.ascontiguousarray(te.indices, np.int32), np.ascontiguousarray(te.data, np.float32)
@@ -160,8 +165,9 @@ def _merge_worker(rank, world, port, out_dir, merge):
     job.run(HYPER, 42, 0, 10)  # exchanges behind iterations 4 and 8, then two local iterations
     res = job.loss(te, u0, u1)
     info = job.info()
+    xs = job.exchange_stats()  # (the driver's exchange timers: one completed event pair per exchange, a ring of 32)
     np.savez(os.path.join(out_dir, "m%d.npz" % rank), P=job.P, Q=job.Q, ub=job.ub, ib=job.ib, exchanges=info["exchanges"], rmse=res["rmse"],
-             n=res["n"], users_total=info["users_total"])
+             n=res["n"], users_total=info["users_total"], timed=xs["timed"], seconds=xs["seconds"], max_seconds=xs["max_seconds"])
     job.close()
     dist.destroy_process_group()
 
@@ -174,6 +180,8 @@ def test_cpp_driver_two_ranks_gloo_against_the_merge_algebra(tmp_path, merge):
     tr, te = synth.make_ratings(80, 25, 900, min_degree=2, seed=5)
     states, bounds, exchanges = _emulate(tr, 6, world, 4, 10, merge)
     assert int(r[0]["exchanges"]) == int(r[1]["exchanges"]) == exchanges == 2
+    for k in range(world):  # every exchange timed, on every rank
+        assert int(r[k]["timed"]) == 2 and 0 < float(r[k]["max_seconds"]) <= float(r[k]["seconds"]) <= 60.0
     assert float(r[0]["users_total"]) == float(np.count_nonzero(np.diff(tr.indptr)))  # the constructor's all-reduce of the totals
     for k in range(world):
         u0, u1 = bounds[k], bounds[k + 1]

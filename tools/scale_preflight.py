@@ -11,10 +11,18 @@
   3. replicas bit-identical: sha256 of every rank's Q and item_bias gathered on rank 0; the global loss equal on every rank;
   4. rank 0 then runs `bin/mf -g N` on a small CSV pair (ranks forked before any HIP call, the id handed around through pipes) and
      checks the exit code and the five output files.
-Prints one PASS / FAIL line per step; exit code 0 only if all passed.  No performance number comes out of this tool."""
+  5. the launcher (which never touches a GPU itself) then runs EXACTLY the driver's command -- `python bench.py --gpus 1 --steps 20
+     --warmup 5`, or for N > 1 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+     bench.py --gpus N --steps 20 --warmup 5` -- as a fresh child in its own process group under a watchdog (--bench-timeout
+     seconds: the whole group is killed and the tool exits non-zero), and checks the JSON line: n_gpus == N, steps / warmup as asked,
+     what RCCL itself reports (rccl.rccl_nranks == N for N > 1), one per_rank record per rank, at least one timed region with an
+     exchange.  --bench-args appends flags (tests: a small workload).
+Prints one PASS / FAIL line per step; exit code 0 only if all passed.  The bench line is echoed, but no number of this tool is a result."""
 import argparse
 import hashlib
+import json
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -24,19 +32,124 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def descendants(pid):
+    """Every live process below pid (children of children ...), by /proc's parent links: torch.distributed.run starts its ranks in
+    sessions of their own, so a process-group kill of the launcher does not reach them."""
+    parent = {}
+    for name in os.listdir("/proc"):
+        if name.isdigit():
+            try:
+                with open("/proc/%s/stat" % name) as fh:
+                    fields = fh.read().rsplit(")", 1)[1].split()
+                parent[int(name)] = int(fields[1])
+            except (OSError, IndexError, ValueError):
+                pass
+    found, frontier = [], [pid]
+    while frontier:
+        nxt = [c for c, p in parent.items() if p in frontier and c not in found]
+        found += nxt
+        frontier = nxt
+    return found
+
+
+def run_watched(cmd, timeout_s, env=None):
+    """A fresh child under a watchdog.  At the limit: the exact processes this call started -- the child and everything below it,
+    listed by pid before any signal -- get SIGTERM (the launcher then takes its ranks down itself), ten seconds, then SIGKILL
+    each.  -> (returncode or None, stdout)."""
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=sys.stderr, text=True, start_new_session=True, env=env)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+        return proc.returncode, out
+    except subprocess.TimeoutExpired:
+        mine = [proc.pid] + descendants(proc.pid)
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            for pid in mine:
+                try:
+                    os.kill(pid, sig)
+                except ProcessLookupError:
+                    pass
+            try:
+                out, _ = proc.communicate(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                out = ""
+        else:
+            proc.stdout.close()  # (someone still holds the pipe: do not wait for it)
+        return None, out or ""
+
+
+def driver_bench(n, timeout_s, extra):
+    """Step 5: the driver's own command line for N GPUs, watched; -> (passed, detail)."""
+    bench = os.path.join(ROOT, "bench.py")
+    tail = ["--gpus", str(n), "--steps", "20", "--warmup", "5"] + extra
+    if n == 1:
+        cmd = [sys.executable, bench] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), bench] + tail
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CU2REC_RCCL_WORLD1"):
+        env.pop(k, None)
+    rc, out = run_watched(cmd, timeout_s, env)
+    if rc is None:
+        return False, "watchdog: no result within %d s, process group killed: %s" % (timeout_s, " ".join(cmd))
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if rc != 0 or len(lines) != 1:
+        return False, "exit code %s, %d JSON line(s): %s" % (rc, len(lines), out[-1500:])
+    line = json.loads(lines[0])
+    print(lines[0], flush=True)
+    problems = []
+    if line.get("n_gpus") != n or line.get("steps") != 20 or line.get("warmup") != 5:
+        problems.append("n_gpus / steps / warmup = %s / %s / %s" % (line.get("n_gpus"), line.get("steps"), line.get("warmup")))
+    if not (line.get("value", 0) > 0 and "roofline" in line):
+        problems.append("no value / roofline")
+    if n > 1:
+        rccl = line.get("rccl") or {}
+        gloo = os.environ.get("CU2REC_BENCH_BACKEND", "nccl") != "nccl"  # (plumbing rehearsal on a one-GPU box: no RCCL on the data path)
+        if not gloo and rccl.get("rccl_nranks") != n:
+            problems.append("RCCL reports %s ranks" % rccl.get("rccl_nranks"))
+        if gloo and not rccl.get("is_callback"):
+            problems.append("gloo rehearsal without the callback communicator")
+        ranks = line.get("per_rank") or []
+        if sorted(r.get("rank") for r in ranks) != list(range(n)):
+            problems.append("per_rank lists %s" % [r.get("rank") for r in ranks])
+        if not gloo and any((r.get("comm") or {}).get("rccl_nranks") != n for r in ranks):
+            problems.append("a rank's communicator is not %d wide" % n)
+        if not line.get("timed_regions_with_exchange"):
+            problems.append("no timed region held an exchange")
+        if (line.get("config") or {}).get("exchanges_in_warmup", 0) < 1:
+            problems.append("no exchange in the warm-up")
+    return not problems, "; ".join(problems) if problems else "value %.4g %s, %d regions, %s with an exchange, exchange mean %s s" % (
+        line["value"], line["unit"], line["timed_regions"], line.get("timed_regions_with_exchange"), (line.get("exchange") or {}).get("mean_seconds"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--bench-timeout", type=int, default=480)
+    ap.add_argument("--bench-args", default="", help="extra flags for step 5's bench.py, space separated")
+    ap.add_argument("--no-bench", action="store_true", help="steps 1-4 only")
+    ap.add_argument("--bench-only", action="store_true", help="step 5 only (rehearsal of N ranks on one GPU: CU2REC_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ:
         if args.gpus == 1:
             os.environ["CU2REC_RCCL_WORLD1"] = "1"
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus)]
-        sys.exit(subprocess.run(cmd).returncode)  # fresh child processes: nothing that touched a GPU is re-executed
+               "--master-port", str(free_port()), os.path.abspath(__file__), "--gpus", str(args.gpus)]
+        rc = 0 if args.bench_only else subprocess.run(cmd).returncode  # fresh child processes: nothing that touched a GPU is re-executed
+        if rc != 0 or args.no_bench:
+            sys.exit(rc)
+        passed, detail = driver_bench(args.gpus, args.bench_timeout, args.bench_args.split())
+        print("%s  the driver's command (bench.py --gpus %d --steps 20 --warmup 5) under a %d s watchdog: %s"
+              % ("PASS" if passed else "FAIL", args.gpus, args.bench_timeout, detail), flush=True)
+        print("PREFLIGHT+BENCH %s" % ("OK" if passed else "FAILED"), flush=True)
+        sys.exit(0 if passed else 1)
 
     import numpy as np
     import torch
@@ -59,7 +172,10 @@ def main():
     check(cu.lib().cu2rec_set_device(local))
     try:
         comm = sharded.Comm(rank, world, share=sharded.share_through_torch(device))
-        report("ncclCommInitRank through cu2rec_comm_create, %d rank(s)" % world, True)
+        ci = comm.info()
+        report("ncclCommInitRank through cu2rec_comm_create, %d rank(s); RCCL %d reports ncclCommCount %d, rank %d, device %d"
+               % (world, ci["rccl_version"], ci["rccl_nranks"], ci["rccl_rank"], ci["rccl_device"]),
+               ci["rccl_nranks"] == world and ci["rccl_rank"] == rank)
     except Exception as e:
         report("ncclCommInitRank through cu2rec_comm_create", False, repr(e))
         sys.exit(1)
