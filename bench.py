@@ -576,22 +576,44 @@ def main():
             import tier2_converged as t2
             t2_iters = 8000
             seq_rec, _ = t2.run_mode(cu, d_train, d_test, f, 42, t2_iters, "ordered")
+            # the CPU oracle's own converged run in the reference's arithmetic (sequential dot, float / double loss sums): NOT recomputed
+            # here (250 s of a host core) -- read from the committed record of tests/test_gpu_blocksolve.py::
+            # test_converged_ml20m_blocksolve_against_the_cpu_oracle_in_the_references_own_arithmetic, which re-runs it in every GPU suite
+            cpu_rec, cpu_file = None, _latest("r[0-9][0-9]_converged_vs_cpu_oracle.json")
+            if cpu_file and args.workload == "ml-20m" and f == 100:
+                with open(os.path.join(ROOT, cpu_file)) as fh:
+                    cpu_rec = json.load(fh)
             t2_modes = {}
             for label in ("blocksolve", "hogwild-resident", "hogwild-streaming"):
                 if label == "hogwild-resident" and L.cu2rec_hogwild_resident_plan(train.rows, f, 500, None, None) != 1:
                     continue
                 rec, _ = t2.run_mode(cu, d_train, d_test, f, 42, t2_iters, label)
                 gap = abs(rec["final_test_rmse"] - seq_rec["final_test_rmse"])
+                at_cpu = next((r for i, r in rec["checks"] if cpu_rec and i == cpu_rec["cpu_oracle_f64"]["checks"][-1]["iteration"]), None)
                 t2_modes[label] = {"final_test_rmse": rec["final_test_rmse"], "min_test_rmse": rec["min_test_rmse"], "decay_iterations": rec["decay_iterations"],
+                                   "gap_to_cpu_oracle_at_its_iterations": None if at_cpu is None else abs(at_cpu - cpu_rec["cpu_oracle_f64"]["final_test_rmse"]),
                                    "final_learning_rate": rec["final_learning_rate"], "converged": rec["converged"], "gap_vs_sequential": gap,
                                    "within_1e-4": bool(gap <= 1e-4)}
                 log("tier 2 converged, %s: gap %.2e" % (label, gap))
             check(L.cu2rec_check_faults())
+            cpu_fields = {}
+            if cpu_rec:
+                n_cpu = cpu_rec["cpu_oracle_f64"]["checks"][-1]["iteration"]
+                at = {label: next((r for i, r in rec_["checks"] if i == n_cpu), None) for label, rec_ in (("sequential", seq_rec),)}
+                cpu_fields = {"cpu_oracle_file": cpu_file, "cpu_oracle_iterations": n_cpu,
+                              "cpu_oracle_final_test_rmse": cpu_rec["cpu_oracle_f64"]["final_test_rmse"],
+                              "cpu_oracle_final_test_rmse_float_accumulators": cpu_rec["cpu_oracle_f32"]["final_test_rmse"],
+                              "cpu_oracle_decay_iterations": cpu_rec["cpu_oracle_f64"]["decay_iterations"],
+                              "test_rmse_at_cpu_oracle_iterations": at["sequential"],
+                              "gap_to_cpu_oracle_at_its_iterations": None if at["sequential"] is None else abs(at["sequential"] - cpu_rec["cpu_oracle_f64"]["final_test_rmse"]),
+                              "cpu_oracle_arithmetic": "oracle/cu2rec_oracle.c orc_train, DOT_SEQ (mf_sequential.cu:122-125), loss sums in double (loss.cu:185-190) / "
+                                                       "float (mf_sequential.cu:147-174: what the reference prints, biased low by %.1e)" % cpu_rec["float_accumulator_bias_of_the_printed_test_rmse"]}
             side["tier2_converged"] = {
                 "what": "converged test RMSE against the sequential (ordered = mf_sequential.cu) run: train() under the reference's schedule, "
                         "%d iterations, sampler seed 42" % t2_iters,
                 "sequential": {"final_test_rmse": seq_rec["final_test_rmse"], "min_test_rmse": seq_rec["min_test_rmse"],
-                               "decay_iterations": seq_rec["decay_iterations"], "final_learning_rate": seq_rec["final_learning_rate"], "converged": seq_rec["converged"]},
+                               "decay_iterations": seq_rec["decay_iterations"], "final_learning_rate": seq_rec["final_learning_rate"], "converged": seq_rec["converged"],
+                               **cpu_fields},
                 "modes": t2_modes, "tolerance": 1e-4,
                 "headline_mode_decision": "value is timed in the fastest mode whose converged gap is <= 1e-4 on every seed: block-solve; the Hogwild forms "
                                           "miss it on every seed (three seeds per mode and the ML-1M shape: profiles/r05_tier2_converged_*.json; "

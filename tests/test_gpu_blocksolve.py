@@ -372,7 +372,7 @@ def test_converged_ml20m_blocksolve_against_the_cpu_oracle_in_the_references_own
     names = ("max_abs_dP", "max_abs_dQ", "max_abs_d_user_bias", "max_abs_d_item_bias")
     diffs = {n: float(np.abs(g.astype(np.float64) - w).max()) for n, g, w in zip(names, (P, Q, ub, ib), state64)}
     rms = {n.replace("max_abs", "rms"): float(np.sqrt(np.mean((g.astype(np.float64) - w) ** 2))) for n, g, w in zip(names, (P, Q, ub, ib), state64)}
-    assert max(diffs.values()) <= 2e-2 and max(rms.values()) <= 1e-3, (diffs, rms)
+    assert max(diffs.values()) <= 1e-3 and max(rms.values()) <= 1e-5, (diffs, rms)  # measured: 4.5e-5 (one Q entry), rms 2.3e-7
     out = {"what": "cu2rec_train(CU2REC_SGD_BLOCKSOLVE) on one MI355X against oracle/cu2rec_oracle.c orc_train (DOT_SEQ) on one host core; "
                    "ml-20m shape f=100, 5000 iterations, reference schedule, seed 42",
            "product": {"checks": checks, "decay_iterations": decays, "final_learning_rate": float(cfg.learning_rate),
