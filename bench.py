@@ -149,18 +149,23 @@ def cpu_baseline(train, test, f, hyper, budget_s=12.0):
 
 # A user-sharded run is NOT the sequential run (the item side is reconciled once per period): what its test RMSE differs by from the
 # N = 1 (= mf_sequential.cu) result, per N -- measured with the PRODUCT's driver at full size (N ranks as threads of one process on one
-# GPU) and pinned by tests/test_gpu_sharded.py (profiles/r05_sharded_converged.txt).
+# GPU) and pinned by tests/test_gpu_sharded.py (profiles/r06_sharded_equal_schedule.txt).
 SHARDED_TOLERANCE = {
     "against": "test RMSE of the N = 1 run (= the sequential result), block-solve per shard, `adaptive` merge, one exchange per epoch",
     "fixed iterations at lr .01": {
         "ml-20m f=100, 1,000 iterations": {"2": {"measured": -1e-5, "accepted": 1e-4}, "4": {"measured": 1.7e-4, "accepted": 3e-4},
                                            "8": {"measured": 3.9e-4, "accepted": 6e-4}},
         "netflix f=128, 660 iterations": {"8": {"measured": -1.2e-3, "accepted": 1.6e-3}}},
-    "converged (reference LR schedule, 8,000 iterations): [end point, best checkpoint]": {
-        "ml-20m f=100": {"2": [-4.3e-3, -4.3e-5], "4": [-3.5e-3, -2.6e-4], "8": [-7.7e-3, -2.7e-4]},
-        "netflix f=128": {"8": [-5.0e-3, 1.8e-3]}},
+    "converged, 8,000 iterations: [end point under the run's OWN patience decisions, end point under the N = 1 run's learning-rate history, best checkpoint]": {
+        "ml-20m f=100": {"2": [-4.3e-3, -4.3e-3, -4.3e-5], "4": [-3.5e-3, -8.0e-3, -2.6e-4], "8": [-7.7e-3, -1.06e-2, -2.7e-4]},
+        "netflix f=128": {"2": [-2.8e-3, -2.6e-3, 2.2e-4], "4": [-9.5e-4, -6.1e-3, 1.4e-3], "8": [-5.0e-3, -8.9e-3, 1.8e-3]},
+        "accepted (tests)": {"ml-20m f=100 N=8": 1.3e-2, "netflix f=128 N=8": 1.1e-2}},
+    "cause": "negative = the sharded run's test RMSE is LOWER: the gap opens where N = 1 overfits (ml-20m: 0.8098 at 1,000 iterations -> 0.8205 frozen); "
+             "hot item rows merged as a weighted mean of N shard-local results overfit more slowly.  Not the patience rule (equal LR histories "
+             "widen the gap), not the exchange period (2 ... 115 iterations: same gap), not the adaptive constant (2 ... 20); an all-reduce "
+             "every iteration with the constant scaled to the period leaves -1.5e-3 at N = 8",
     "north_star_bar": 1e-4, "meets_north_star_bar": "N <= 2 only (fixed iterations)",
-    "survey_8e_bar": "converged <= 1e-3 of N = 1: met at the best checkpoint on the ML-20M shape, not at the schedule's end point, not on the Netflix shape"}
+    "survey_8e_bar": "converged <= 1e-3 of N = 1: NOT met at the end point under either schedule; met at the best checkpoint on the ML-20M shape only"}
 
 # rocprofv3 --pmc summaries (tools/pmc_summary.py) of THIS workload and mode, if one is committed: (workload, factors, mode) -> file
 def _latest(pattern):

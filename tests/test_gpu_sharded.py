@@ -209,13 +209,16 @@ class _InProcessWorld:
         self.barrier = threading.Barrier(n)
         self.hip = C.CDLL("libamdhip64.so")
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         self.errors = []
 
     def allreduce_for(self, rank):
         def allreduce(ctx, buf, count, is_double, stream):
             try:
                 host = np.empty(count, np.float64 if is_double else np.float32)
-                if self.hip.hipMemcpy(host.ctypes.data, buf, host.nbytes, 2) != 0:  # (synchronous: behind the kernels that filled it)
+                # the header's contract: "ordered on `stream` or synchronising it" -- wait for the kernels that filled the buffer on
+                # THAT stream (whatever it is), then copy
+                if self.hip.hipStreamSynchronize(stream) != 0 or self.hip.hipMemcpy(host.ctypes.data, buf, host.nbytes, 2) != 0:
                     return 1
                 self.slots[rank] = host
                 self.barrier.wait(timeout=600)
@@ -252,10 +255,36 @@ class _InProcessWorld:
         return out
 
 
-def _sharded_run(workload, f, n, merge="adaptive", sync=0, iters=0, converged_iters=0):
+def forced_segments(checks, decays, lr0=0.01, decay=0.2):
+    """The learning-rate history of a finished train() run as segments [(end iteration, rate of the iterations up to it)]: the rate
+    changes BEHIND the check at which the patience ran out (training.cu:146-155), in float like the schedule's own product."""
+    out, lr = [], np.float32(lr0)
+    for it, _ in checks:
+        out.append((int(it), float(lr)))
+        if it in decays:
+            lr = np.float32(lr * np.float32(decay))
+    return out
+
+
+def replay_decays(checks, patience=2):
+    """training.cu:129,146-155 on a run's logged validation RMSEs -> the iterations at which the rate decayed."""
+    last, cur, decays = np.float32(np.finfo(np.float32).max), patience, []
+    for it, r in checks:
+        if last < np.float32(r):
+            cur -= 1
+        if cur <= 0:
+            cur = patience
+            decays.append(int(it))
+        last = np.float32(r)
+    return decays
+
+
+def _sharded_run(workload, f, n, merge="adaptive", sync=0, iters=0, converged_iters=0, forced=None):
     """The product's sharded driver on N shards of a BASELINE shape (in-process world above): block-solve per shard, `merge`,
     exchange every `sync` iterations (0: one epoch).  iters > 0: cu2rec_shard_job_run for that many iterations at lr .01, then an
-    exchange; converged_iters > 0: cu2rec_train_sharded under the reference's schedule (check every 500, patience 2, decay 0.2).
+    exchange; converged_iters > 0: cu2rec_train_sharded under the reference's schedule (check every 500, patience 2, decay 0.2);
+    forced = [(end iteration, rate)]: cu2rec_shard_job_run segment by segment with GIVEN rates (another run's learning-rate history),
+    an exchange and the global test loss behind every segment -- what train() does, minus its own patience decisions.
     -> (global test RMSE, exchanges, replicas identical, final learning rate)."""
     import bench
     train, test = bench.load_dataset(workload, 20240917, 0, lambda: None)
@@ -276,6 +305,16 @@ def _sharded_run(workload, f, n, merge="adaptive", sync=0, iters=0, converged_it
             rmse, lr = float(losses[converged_iters - 1]), float(cfg.learning_rate)
             extra = {"min": float(np.nanmin(losses)), "at": int(np.nanargmin(losses)) + 1,
                      "checks": [(int(i) + 1, float(v)) for i, v in enumerate(losses) if np.isfinite(v)]}
+        elif forced:
+            checks, it = [], 0
+            for end, lr in forced:
+                job.run((lr,) + HYPER[1:], 42, it, end - it, mode="blocksolve")
+                job.exchange()
+                checks.append((end, job.loss(d_te)["rmse"]))
+                it = end
+            rmse = checks[-1][1]
+            best = min(checks, key=lambda c: c[1])
+            extra = {"min": best[1], "at": best[0], "checks": checks}
         else:
             job.run(HYPER, 42, 0, iters, mode="blocksolve")
             job.exchange()
@@ -338,44 +377,75 @@ def test_sharded_driver_weighted_merge_is_the_bar_adaptive_beats_at_n8():
     assert abs(rmse_a - ref) < abs(rmse_w - ref), (rmse_a - ref, rmse_w - ref)  # measured +3.9e-4 against +1.07e-3
 
 
-def test_sharded_driver_converged_n8_ml20m_against_survey_8e_bar():
-    """SURVEY.md section 8e's own bar -- "converged test RMSE ... <= 1e-3 of N = 1" -- measured with the product's train() over all
-    ranks: cu2rec_train_sharded on 8 shards of the ML-20M shape (f=100) under the reference's schedule (8,000 iterations: the rate
-    decays six times, lr < 1e-5) against cu2rec_train on the whole set; both take their own patience decisions on their own GLOBAL
-    test RMSE.  The outcome, pinned either way (profiles/r05_sharded_converged.txt has N = 2 / 4 / 8):
-      * at the schedule's END the bar is NOT met: the sharded run freezes 7.7e-3 BELOW the unsharded one (0.81279 against 0.82048;
-        N = 2 / 4: -4.3e-3 / -3.5e-3) -- eight replicas reconciled once per epoch overfit more slowly, their test RMSE turns up a
-        check later, and where a run freezes under the patience rule depends on WHICH check its test RMSE turns at (the same
-        mechanism that puts converged Hogwild runs 2.5e-3 ... 8.3e-3 apart, test_gpu_blocksolve.py);
-      * at the BEST checkpoint (the minimum of the logged test RMSE, what a user would keep) it is met: -2.7e-4."""
-    ref, ref_lr = _unsharded("ml-20m", 100, converged_iters=8000)
-    ref_min = _unsharded.last_extra["min"]
-    rmse, exchanges, same, lr = _sharded_run("ml-20m", 100, 8, converged_iters=8000)
-    best = _sharded_run.last_extra["min"]
-    assert ref_lr < 1e-5 and lr < 1e-5, (ref_lr, lr)  # both have converged in the schedule's sense
-    assert same and exchanges >= 8000 // 115
-    assert abs(best - ref_min) <= 1e-3, (best, ref_min)
-    assert -1.2e-2 <= rmse - ref <= -1e-3, (rmse, ref)
+_CONVERGED = {}
 
 
-def test_sharded_driver_netflix_f128_n8_fixed_iterations_and_converged():
-    """BASELINE.json configs[4] by the product's driver (Netflix shape, f=128, 8 shards, wire 17,770 x 129 floats): (i) 660
-    iterations, exchange every epoch (165): the sharded run sits 1.2e-3 BELOW the sequential run at that point of the trajectory
-    (nearly every item is updated many times per iteration by every shard: the adaptive merge is the mean there) -- pinned with its
-    sign, |gap| <= 1.6e-3; (ii) CONVERGED under the reference's schedule (8,000 iterations, lr < 1e-5 on both): the end point 5.0e-3
-    below N = 1 (0.85052 against 0.85549), the best checkpoint 1.8e-3 ABOVE (0.84418 at 2,000 against 0.84242 at 1,500) -- both
-    OUTSIDE SURVEY 8e's 1e-3, pinned as measured."""
+def _converged_pair(workload, f, n, iters=8000):
+    """(N = 1 record, sharded record) of one shape: cu2rec_train on the whole set under the reference's schedule, then N shards driven
+    through the SAME learning-rate history (forced_segments: equal LR histories -- what is left is the merge, not the patience rule's
+    chaos; profiles/r06_sharded_equal_schedule.txt has the own-schedule runs beside them).  Cached: two tests read each pair."""
+    key = (workload, f, n, iters)
+    if key not in _CONVERGED:
+        ref, ref_lr = _unsharded(workload, f, converged_iters=iters)
+        e0 = dict(_unsharded.last_extra)
+        decays = replay_decays(e0["checks"])
+        rmse, exchanges, same, _ = _sharded_run(workload, f, n, forced=forced_segments(e0["checks"], decays))
+        e = dict(_sharded_run.last_extra)
+        _CONVERGED[key] = ({"final": ref, "lr": ref_lr, "decays": decays, **e0}, {"final": rmse, "exchanges": exchanges, "same": same, **e})
+    return _CONVERGED[key]
+
+
+def test_sharded_driver_converged_n8_ml20m_under_equal_lr_histories():
+    """BASELINE.json configs[3] converged, by the product's driver: 8 shards of the ML-20M shape (f=100) driven through the N = 1 run's
+    own learning-rate history (8,000 iterations of the reference's schedule: six decays, lr < 1e-5), so that the two runs differ by
+    the MERGE only.  Measured (profiles/r06_sharded_equal_schedule.txt): end point -1.06e-2 (0.80992 against 0.82048), best checkpoint
+    -5.1e-4.  Cause, named: the gap opens only where N = 1 overfits (test RMSE 0.8098 at 1,000 -> 0.8205 frozen); N replicas whose hot
+    item rows are merged as a weighted mean of shard-local results overfit more slowly -- the sharded run's test RMSE is LOWER.  Neither
+    the exchange period (2 ... 115: same gap), nor the adaptive constant (2 ... 20), nor the patience rule (own schedule: -7.7e-3)
+    closes it; an all-reduce EVERY iteration with the constant scaled to the period still leaves -1.5e-3.  Asserted: the honest
+    per-N tolerance that IS met (|gap| <= 1.3e-2), the sign, the best checkpoint inside 1e-3, agreement before the overfitting
+    (|gap| <= 6e-4 at 1,000), identical replicas.  SURVEY 8e's own bar is the xfail test below."""
+    n1, sh = _converged_pair("ml-20m", 100, 8)
+    assert n1["lr"] < 1e-5 and len(n1["decays"]) >= 5, n1
+    assert sh["same"] and sh["exchanges"] >= 8000 // 115
+    gap = sh["final"] - n1["final"]
+    assert abs(gap) <= 1.3e-2 and gap < 0, gap
+    assert abs(sh["min"] - n1["min"]) <= 1e-3, (sh["min"], n1["min"])
+    at_1000 = dict(sh["checks"])[1000] - dict(n1["checks"])[1000]
+    assert abs(at_1000) <= 6e-4, at_1000
+
+
+def test_sharded_driver_converged_netflix_f128_n8_under_equal_lr_histories():
+    """BASELINE.json configs[4] by the product's driver (Netflix shape, f=128, 8 shards, wire 17,770 x 129 floats) through the N = 1
+    run's learning-rate history (8,000 iterations, five decays).  Measured: end point -8.9e-3 (0.84661 against 0.85549), best checkpoint
+    +1.8e-3 (0.84418 at 2,000 against 0.84242 at 1,500: the checks are 500 iterations apart and the sharded minimum falls between
+    two).  Same cause as on the ML-20M shape; asserted: the per-N tolerance that is met (|gap| <= 1.1e-2), its sign, the best
+    checkpoint within 2.5e-3, identical replicas."""
+    n1, sh = _converged_pair("netflix", 128, 8)
+    assert n1["lr"] < 1e-4 and len(n1["decays"]) >= 4, n1
+    assert sh["same"] and sh["exchanges"] >= 8000 // 165
+    gap = sh["final"] - n1["final"]
+    assert abs(gap) <= 1.1e-2 and gap < 0, gap
+    assert abs(sh["min"] - n1["min"]) <= 2.5e-3, (sh["min"], n1["min"])
+
+
+@pytest.mark.xfail(strict=False, reason="SURVEY 8e's bar -- converged test RMSE within 1e-3 of N = 1 -- is NOT met by a user-sharded run: "
+                                        "-1.06e-2 (ML-20M, N=8) / -8.9e-3 (Netflix, N=8) under equal LR histories; the merge of N shard-local "
+                                        "results of a hot item row is not mf_sequential.cu's chain (profiles/r06_sharded_equal_schedule.txt)")
+@pytest.mark.parametrize("workload,f", [("ml-20m", 100), ("netflix", 128)])
+def test_sharded_driver_converged_n8_meets_survey_8e_bar(workload, f):
+    n1, sh = _converged_pair(workload, f, 8)
+    assert abs(sh["final"] - n1["final"]) <= 1e-3, sh["final"] - n1["final"]
+
+
+def test_sharded_driver_netflix_f128_n8_fixed_iterations():
+    """BASELINE.json configs[4], fixed iterations: 660 (four epochs of 165), exchange every epoch: the sharded run sits 1.2e-3 BELOW the
+    sequential run at that point of the trajectory (nearly every item is updated many times per iteration by every shard: the adaptive
+    merge is the mean there) -- |gap| <= 1.6e-3, replicas identical, the exchange count is the cadence's."""
     ref, _ = _unsharded("netflix", 128, iters=660)
     rmse, exchanges, same, _ = _sharded_run("netflix", 128, 8, iters=660)
     assert same and exchanges == 660 // 165  # (the run ends ON an exchange of the cadence: the one asked for behind it has nothing to do)
-    assert -1.6e-3 <= rmse - ref <= 0.0, rmse - ref
-    ref_c, ref_lr = _unsharded("netflix", 128, converged_iters=8000)
-    ref_min = _unsharded.last_extra["min"]
-    rmse_c, _, same_c, lr = _sharded_run("netflix", 128, 8, converged_iters=8000)
-    best = _sharded_run.last_extra["min"]
-    assert same_c and ref_lr < 1e-5 and lr < 1e-5, (ref_lr, lr)
-    assert -1e-2 <= rmse_c - ref_c <= -1e-3, (rmse_c, ref_c)
-    assert 0.0 <= best - ref_min <= 2.5e-3, (best, ref_min)
+    assert abs(rmse - ref) <= 1.6e-3, rmse - ref
 
 
 def test_bench_self_launches_its_ranks(tmp_path):
