@@ -670,6 +670,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_over_algorithmic": (traffic / (users_active * bytes_per_update)) if traffic else None,
                          "traffic_from_profile": traffic_src,
+                         "launch_topology": None if mode != "blocksolve" else {
+                             "timed_region": dict(zip(("form", "why"), cu.api.blocksolve_topology())),
+                             "traffic_profile": "EVENT topology: a rocprofv3 --pmc pass serialises kernels across streams, so the library forks / joins the "
+                                                "side stream with events there (same kernels, same bytes; the pass is for counters, never for timing)"},
                          "kernels": profile_kernels(args.workload, f, mode),
                          "kernel": kernels.get(mode, mode), "bytes_per_update": bytes_per_update,
                          "algorithmic_bytes": alg_bytes, "device_seconds": elapsed_dev,

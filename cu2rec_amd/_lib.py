@@ -103,6 +103,7 @@ SIGNATURES = {
                                                C.c_int, C.POINTER(Hyper), C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "cu2rec_blocksolve_min_rate": (C.c_float, [C.c_float]),
     "cu2rec_blocksolve_lookahead_blocks": (C.c_int, [C.c_int]),
+    "cu2rec_blocksolve_topology": (C.c_int, [C.c_char_p, C.c_size_t]),
     "cu2rec_csr_blocksolve_items": (C.c_int, [_P]),
     "cu2rec_debug_blocksolve_stamps": (C.c_int, [_P, C.c_int]),
     "cu2rec_loss_workspace_bytes": (C.c_size_t, []),

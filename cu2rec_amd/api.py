@@ -401,6 +401,13 @@ def blocksolve_lookahead_blocks(blocks=-1):
     return lib().cu2rec_blocksolve_lookahead_blocks(int(blocks))
 
 
+def blocksolve_topology():
+    """cu2rec_blocksolve_topology -> ("device" | "events" | None before the first block-solve call, the reason)."""
+    buf = C.create_string_buffer(512)
+    mode = lib().cu2rec_blocksolve_topology(buf, len(buf))
+    return {2: "device", 0: "events"}.get(mode), buf.value.decode(errors="replace")
+
+
 def loss_raw(indptr, indices, data, n_rows, nnz, P, ldp, Q, ldq, user_bias, item_bias, global_bias, n_factors,
              workspace, errors_out=None, stream=None):
     sa, ss, mae, rmse = C.c_double(), C.c_double(), C.c_float(), C.c_float()

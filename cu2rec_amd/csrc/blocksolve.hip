@@ -1455,6 +1455,118 @@ BsFault &fault_for_current_device() {  // caller holds g_fault_mutex
 }
 }  // namespace
 
+// ---- the launch topology of an iteration's fork / join, per device: decided on first use, revisable ------------------------------
+// kBsTopoDevice: gate kernel + device-side join (cross-stream spin waits: they need kernels of the two streams RUNNING SIDE BY SIDE);
+// kBsTopoEvents: events both ways (works wherever HIP works; 5.4 + 2.5-3.3 us per iteration on the main stream).  What decides:
+//   1. CU2REC_BS_GATE in the environment (0: events, anything else: device) -- a force, never revised;
+//   2. a counter pass of rocprofv3 (--pmc exports ROCPROF_COUNTER_COLLECTION: kernels are serialised across streams): events;
+//   3. otherwise a two-stream handshake PROBE on the very streams the iterations will use (bs_probe_streams below): a wait kernel queued
+//      FIRST on one stream, satisfied by a signal kernel queued behind it on the other, bounded by 10 ms -- both directions.  Streams
+//      that share a hardware queue (GPU_MAX_HW_QUEUES=1), a tool that serialises dispatches, a tenant holding the CUs: the waiter times
+//      out, and the process uses events for good;
+//   4. a join that gives up mid-run (bs_check_fault) switches the device to events for every later call, and says so in its error.
+namespace {
+struct BsTopology {
+    int mode = -1;  // -1: not decided yet
+    bool forced = false;
+    std::string why = "not decided yet";
+};
+std::mutex g_topo_mutex;
+std::vector<BsTopology> g_topo;  // per device
+
+__global__ void bs_probe_wait_kernel(const unsigned *word, unsigned *result, unsigned long long ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    unsigned seen = 0;
+    for (;;) {
+        if (ld_agent(word) != 0u) {
+            seen = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > ticks) break;
+    }
+    __hip_atomic_store(result, seen ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void bs_probe_signal_kernel(unsigned *word) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Do kernels of `waiter` and `signaller` run side by side?  The waiter is queued FIRST: if the two streams are served one after the
+// other it can only time out (10 ms), and the signal kernel runs behind it.  Every wave reaches its exit: the wait is bounded.
+bool bs_probe_streams(hipStream_t waiter, hipStream_t signaller, unsigned *scratch) {
+    CU2REC_HIP(hipMemsetAsync(scratch, 0, 64 * sizeof(unsigned), waiter));
+    CU2REC_HIP(hipStreamSynchronize(waiter));
+    CU2REC_HIP(hipStreamSynchronize(signaller));
+    hipLaunchKernelGGL(bs_probe_wait_kernel, dim3(1), dim3(64), 0, waiter, scratch, scratch + 32, 1000000ull);  // 10 ms of the 100 MHz clock
+    hipLaunchKernelGGL(bs_probe_signal_kernel, dim3(1), dim3(64), 0, signaller, scratch);
+    CU2REC_HIP(hipGetLastError());
+    CU2REC_HIP(hipStreamSynchronize(waiter));
+    CU2REC_HIP(hipStreamSynchronize(signaller));
+    unsigned result = 0;
+    CU2REC_HIP(hipMemcpy(&result, scratch + 32, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return result == 1u;
+}
+
+BsTopology &topology_for_current_device() {  // caller holds g_topo_mutex
+    int dev = 0;
+    CU2REC_HIP(hipGetDevice(&dev));
+    if (static_cast<int>(g_topo.size()) <= dev) g_topo.resize(dev + 1);
+    return g_topo[dev];
+}
+}  // namespace
+
+int bs_topology(hipStream_t stream, hipStream_t side) {
+    std::lock_guard<std::mutex> lock(g_topo_mutex);
+    BsTopology &t = topology_for_current_device();
+    if (t.mode >= 0) return t.mode;
+    if (const char *env = std::getenv("CU2REC_BS_GATE")) {
+        t.mode = std::atoi(env) != 0 ? kBsTopoDevice : kBsTopoEvents;
+        t.forced = true;
+        t.why = std::string("CU2REC_BS_GATE=") + env;
+        return t.mode;
+    }
+    if (const char *pmc = std::getenv("ROCPROF_COUNTER_COLLECTION"))
+        if (*pmc && std::string(pmc) != "0" && std::string(pmc) != "False" && std::string(pmc) != "false") {
+            t.mode = kBsTopoEvents;
+            t.why = "a rocprofv3 counter pass (ROCPROF_COUNTER_COLLECTION) serialises kernels across streams";
+            return t.mode;
+        }
+    unsigned *scratch = nullptr;
+    CU2REC_HIP(hipMalloc(reinterpret_cast<void **>(&scratch), 64 * sizeof(unsigned)));
+    bool forward = false, backward = false;
+    try {
+        forward = bs_probe_streams(stream, side, scratch);
+        backward = forward && bs_probe_streams(side, stream, scratch);
+    } catch (...) {
+        (void)hipFree(scratch);
+        throw;
+    }
+    (void)hipFree(scratch);
+    if (forward && backward) {
+        t.mode = kBsTopoDevice;
+        t.why = "two-stream handshake probe passed in both directions";
+    } else {
+        t.mode = kBsTopoEvents;
+        t.why = std::string("two-stream handshake probe: a wait kernel on the ") + (forward ? "side" : "main") +
+                " stream was not reached by the other stream's signal kernel within 10 ms (the streams do not run side by side here)";
+    }
+    return t.mode;
+}
+
+int bs_topology_query(std::string *why) {
+    std::lock_guard<std::mutex> lock(g_topo_mutex);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    if (dev >= static_cast<int>(g_topo.size())) return -1;
+    if (why) *why = g_topo[dev].why;
+    return g_topo[dev].mode;
+}
+
 void bs_set_stamps(unsigned long long *buf, int cap) {
     g_stamps = buf;
     g_stamps_cap = buf ? cap : 0;
@@ -1489,10 +1601,27 @@ void bs_check_fault() {
         (void)hipDeviceSynchronize();  // reported once: cleared so that the process can go on
         (void)hipMemset(f.dev_word, 0, sizeof(unsigned));
         *f.host_word = 0;
+        // self-healing: whatever kept the launches from running side by side will do so again -- every later block-solve call of
+        // this process on this device forks and joins with events (unless the environment forces the device form)
+        bool switched = false;
+        {
+            std::lock_guard<std::mutex> topo_lock(g_topo_mutex);
+            if (static_cast<int>(g_topo.size()) <= dev) g_topo.resize(dev + 1);
+            if (!g_topo[dev].forced && g_topo[dev].mode != kBsTopoEvents) {
+                g_topo[dev].mode = kBsTopoEvents;
+                g_topo[dev].why = "a device-side join gave up mid-run: switched to the event fork / join";
+                switched = true;
+            }
+        }
         fail(CU2REC_EHIP,
-             "cu2rec_amd: a block-solve iteration gave up waiting for one of its own launches (the three phases of an iteration "
-             "run side by side and hand blocks over through flags: is another process or stream holding this GPU's compute "
-             "units?); the model state is undefined.  CU2REC_SGD_ORDERED is the same result without concurrent launches");
+             std::string("cu2rec_amd: a block-solve iteration gave up waiting for one of its own launches (the three phases of an iteration "
+                         "run side by side and hand blocks over through flags: is another process or stream holding this GPU's compute "
+                         "units?); the model state is undefined.  ") +
+                 (switched ? "From here on this process forks and joins the iteration's streams with events instead of device-side waits "
+                             "(slower by a few microseconds per iteration, independent of concurrent execution): re-create the model and "
+                             "run again.  "
+                           : "(CU2REC_BS_GATE forces the device-side form: unset it to let the library fall back to events.)  ") +
+                 "CU2REC_SGD_ORDERED is the same result without concurrent launches");
     }
 }
 

@@ -2,6 +2,8 @@
 // (mf_sequential.cu:102-143) with the long item chains solved block-wise; see blocksolve.hip.
 #pragma once
 
+#include <string>
+
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -85,6 +87,11 @@ int bs_compute_units();       // of the current device
 unsigned *bs_status_word();
 void bs_report_status(hipStream_t stream);
 void bs_check_fault();
+// the fork / join topology of this device's iterations (blocksolve.hip, "the launch topology"): decided on first use -- environment,
+// counter pass, or a two-stream handshake probe on the iterations' own streams -- and switched to events by a join that gave up
+constexpr int kBsTopoEvents = 0, kBsTopoDevice = 2;
+int bs_topology(hipStream_t stream, hipStream_t side);
+int bs_topology_query(std::string *why);  // -1: not decided yet
 void bs_launch_tables(const SgdHyper &h, float *tables, hipStream_t stream);
 // one workgroup per iteration of the batch: chain and block descriptors
 void bs_launch_plan(const uint32_t *keys, int n_active, int n_batch, int n_hot, int item_bits, int max_blocks,

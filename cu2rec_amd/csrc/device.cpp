@@ -563,6 +563,17 @@ int cu2rec_sgd_update_blocksolve(cu2rec_schedule *schedule, const int *indptr, c
 float cu2rec_blocksolve_min_rate(float rate) { return blocksolve_min_rate(rate); }
 int cu2rec_blocksolve_lookahead_blocks(int blocks) { return blocksolve_lookahead_blocks(blocks); }
 
+int cu2rec_blocksolve_topology(char *why, size_t cap) {
+    std::string text;
+    const int mode = bs_topology_query(&text);
+    if (why && cap) {
+        const size_t n = std::min(text.size(), cap - 1);
+        std::memcpy(why, text.data(), n);
+        why[n] = 0;
+    }
+    return mode;
+}
+
 int cu2rec_csr_blocksolve_items(const cu2rec_csr *train) {
     int n = -1;
     const int rc = guarded([&] {

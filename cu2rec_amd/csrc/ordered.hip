@@ -798,21 +798,6 @@ OrderedSchedule::~OrderedSchedule() {
         if (e) (void)hipEventDestroy(e);
 }
 
-// How the block-solve mode forks and joins its side stream: 2 (default) gate kernel + device-side join, 0 events both ways.
-// CU2REC_BS_GATE in the environment decides; without it, a process running under a COUNTER pass of rocprofv3 (--pmc: the tool exports
-// ROCPROF_COUNTER_COLLECTION) takes 0 -- a counter pass serialises kernels across streams, and the device-side join would wait for a
-// signal kernel the profiler does not let run before the waiting kernel has ended.  Same kernels, same bytes, same results
-// (tests/test_gpu_blocksolve.py runs both).
-int bs_gate_mode() {
-    static const int mode = [] {
-        if (const char *env = std::getenv("CU2REC_BS_GATE")) return std::atoi(env) != 0 ? 2 : 0;
-        if (const char *pmc = std::getenv("ROCPROF_COUNTER_COLLECTION"))
-            if (*pmc && std::string(pmc) != "0" && std::string(pmc) != "False" && std::string(pmc) != "false") return 0;
-        return 2;
-    }();
-    return mode;
-}
-
 namespace {
 std::atomic<int> g_bs_lookahead{-1};  // -1: not yet initialised from the environment
 }
@@ -979,17 +964,17 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             // (bs_solve_kernel: one workgroup per chain) -> phase 3 (bs_update_kernel: the user side); side stream `upd`: the other
             // items' chains (two-wave form / walk), forked behind phase 1 -- beside it their thousands of workgroups take the CUs
             // from phase 1's (measured: 71 instead of 19 us) -- and joined in front of the next phase 1, which reads rows they write.
-            //  * default (bs_gate_mode() == 2), no event on the main stream: phase 1's workgroups count themselves through, phase 2's
+            //  * default (bs_topology() == kBsTopoDevice: blocksolve.hip, "the launch topology"), no event on the main stream: phase 1's workgroups count themselves through, phase 2's
             //    count themselves in, ONE wavefront queued in front of the side kernel (bs_gate_kernel) ends when both counts have
             //    reached what the host has launched so far; a signal kernel behind the side kernel stores the iteration's number and
             //    one extra workgroup of phase 3's launch waits for it.  Host order gram, solve, gate, side, signal, update: every
             //    launch behind what it waits for (streams sharing a hardware queue serialise, they cannot wait for each other).
-            //  * events (mode 0; what a rocprofv3 counter pass gets): fork on phase 1's completion signal, join by an event wait in
+            //  * events (kBsTopoEvents: a counter pass, streams that do not run side by side, after a join that gave up): fork on phase 1's completion signal, join by an event wait in
             //    front of the next phase 1 (5.4 + 2.5-3.3 us per iteration on the main stream: DESIGN.md section 4).
             const double la = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.q_reg));
             const double lc = std::log2(1.0 - static_cast<double>(a.h.lr) * static_cast<double>(a.h.ib_reg));
             unsigned *status = bs_status_word();
-            const bool device_join = bs_gate_mode() != 0 && max_blocks > 0;
+            const bool device_join = max_blocks > 0 && bs_topology(stream, upd) == kBsTopoDevice;
             bool upd_pending = false;  // (event join) the side kernel of an earlier iteration of this batch has not been waited for yet
 #ifdef CU2REC_TEST_HOOKS  // fault-path tests only (build/test/libcu2rec_amd_hooks.so): 16 the signal is never sent, 32 the gate can never open
             static const int dbg = std::getenv("CU2REC_BS_DBG") ? std::atoi(std::getenv("CU2REC_BS_DBG")) : 0;

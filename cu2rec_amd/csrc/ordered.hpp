@@ -96,7 +96,6 @@ float blocksolve_min_rate(float rate);
 float blocksolve_min_rate_base();   // the explicit value, or the default the automatic scaling starts from
 bool blocksolve_min_rate_is_set();  // by the caller or the environment; otherwise a schedule scales the default with its set
 
-int bs_gate_mode();  // fork / join of the block-solve mode's side stream (CU2REC_BS_GATE; 0 under a rocprofv3 counter pass)
 // chains EXPECTED to be at least this many blocks of 64 links long run phase 2 in the look-ahead form (default 24: the top chains; 0: none;
 // schedules created later); blocks < 0 only queries
 int blocksolve_lookahead_blocks(int blocks);

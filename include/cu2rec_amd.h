@@ -267,12 +267,19 @@ int cu2rec_sgd_update_ordered(cu2rec_schedule *schedule, const int *indptr, cons
                               void *stream);
 
 /* cu2rec_sgd_update in CU2REC_SGD_BLOCKSOLVE mode on raw device pointers (same arguments as the ordered form).
- * Launch topology: an iteration is phases 1-3 on `stream` and the other items' chains on a side stream of the schedule's, forked and
- * joined on the DEVICE (a gate kernel, a signal kernel and one waiting workgroup: no event on the main stream).  UNDER A COUNTER PASS
- * OF rocprofv3 (--pmc; the tool exports ROCPROF_COUNTER_COLLECTION) THE LIBRARY SWITCHES TO AN EVENT FORK / JOIN BY ITSELF: a counter
- * pass serialises kernels across streams, and the device-side join would wait for a signal kernel the profiler has not let run.  Same
- * kernels, same bytes, same results (tests/test_gpu_blocksolve.py runs both); 3-6 us per iteration slower, so a --pmc pass is for
- * counters, never for timing.  CU2REC_BS_GATE=0 / 1 in the environment forces the event / device form.
+ * Launch topology: an iteration is phases 1-3 on `stream` and the other items' chains on a side stream of the schedule's.  Two forms,
+ * same kernels, same bytes, same results (tests/test_gpu_blocksolve.py runs both): DEVICE -- fork and join by a gate kernel, a signal
+ * kernel and one waiting workgroup, no event on the main stream; needs kernels of the two streams running SIDE BY SIDE -- and EVENTS
+ * (3-6 us per iteration slower; works wherever HIP works).  The library picks per device, on the first block-solve call:
+ *   1. CU2REC_BS_GATE=0 / 1 in the environment forces events / device;
+ *   2. under a counter pass of rocprofv3 (--pmc; the tool exports ROCPROF_COUNTER_COLLECTION: kernels are serialised across streams):
+ *      events -- so a --pmc pass is for counters, never for timing;
+ *   3. otherwise a two-stream handshake probe on the streams the iterations will use (a wait kernel queued first on one, satisfied by a
+ *      signal kernel on the other, 10 ms bound, both directions): streams sharing one hardware queue (GPU_MAX_HW_QUEUES=1), a tool that
+ *      serialises dispatches, another tenant holding the compute units all end in events;
+ *   4. a join that gives up mid-run (CU2REC_EHIP from the call or cu2rec_check_faults: the model state is undefined) switches the
+ *      device to events for every later call of the process, and the error text says so.
+ * cu2rec_blocksolve_topology reports what is in force.
  * Environment knobs the library reads (all optional, read once per process): CU2REC_RESIDENT (Hogwild launch form), CU2REC_BLOCKSOLVE_RATE,
  * CU2REC_BLOCKSOLVE_LOOKAHEAD, CU2REC_BS_GATE, CU2REC_BS_WAIT_S (block-solve mode), CU2REC_READER_THREADS, CU2REC_RATINGS_CACHE (ingest),
  * CU2REC_COMM_TIMEOUT_S, CU2REC_MERGE_ADAPTIVE_C, CU2REC_RCCL_WORLD1 (sharded driver; the last one a debugging aid: a real one-rank
@@ -300,6 +307,9 @@ float cu2rec_blocksolve_min_rate(float rate);
  * up to float rounding.  Process-wide, read when a schedule is created (like cu2rec_blocksolve_min_rate); 0 = off;
  * CU2REC_BLOCKSOLVE_LOOKAHEAD in the environment sets the initial value.  Returns the previous value; blocks < 0 only queries. */
 int cu2rec_blocksolve_lookahead_blocks(int blocks);
+/* The fork / join form in force on the current device (see cu2rec_sgd_update_blocksolve): 2 device-side gate and join, 0 events,
+ * -1 not decided yet (no block-solve call so far).  `why` (may be NULL): the reason, NUL-terminated, truncated to `cap` bytes. */
+int cu2rec_blocksolve_topology(char *why, size_t cap);
 /* Development aid: while `buffer` (device memory, 8 * (1 + 8 * capacity) bytes, zeroed by the caller) is set, every
  * wavefront of the block-solve kernels writes {kernel, id, start, end, 4 marks (trace builds)} in ticks of the 100 MHz device clock into record
  * kernel * (capacity / 8) + id (kernel: 1 gram, 2 solver, 3 loader, 4 update, 7 cross blocks; records never written stay

@@ -467,8 +467,18 @@ try:
     model.sgd(d_tr, hyper, 42, 0, iters, mode="blocksolve")
     check(lib().cu2rec_check_faults())
 except Cu2recError as e:
-    print("STATUS", e.status, "gave up" in str(e))
+    print("STATUS", e.status, "gave up" in str(e), "with events instead" in str(e))
+    # self-healing: the process has switched to the event fork / join -- a fresh model, the same call, the oracle's result
+    assert api.blocksolve_topology()[0] == "events", api.blocksolve_topology()
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    model.sgd(d_tr, hyper, 42, 0, iters, mode="blocksolve")
+    check(lib().cu2rec_check_faults())
+    state = orc.init_model(tr.rows, tr.cols, f)
+    orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias), *state, tr.global_bias, hyper, 42, 0,
+                       iters, dot_order=orc.DOT_TREE16)
+    print("HEALED %%.3e" %% max(float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(model.download(), state)))
     sys.exit(0)
+assert api.blocksolve_topology()[0] == "device", api.blocksolve_topology()  # (the probe passed: nothing serialises the streams here)
 state = orc.init_model(tr.rows, tr.cols, f)
 orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias), *state, tr.global_bias, hyper, 42, 0,
                    iters, dot_order=orc.DOT_TREE16)
@@ -486,22 +496,26 @@ def _run_fault_script(dbg):
     res = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                          text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-3000:]
-    return res.stdout.strip().splitlines()[-1]
+    return res.stdout.strip().splitlines()
 
 
-def test_blocksolve_join_wait_that_is_never_satisfied_ends_in_ehip():
+def test_blocksolve_join_wait_that_is_never_satisfied_ends_in_ehip_and_the_process_heals():
     """The default launch topology's join: phase 3 carries one workgroup that waits for the number a signal kernel behind the side
     kernel stores.  With the signal never sent (CU2REC_BS_DBG=16) and the waits' bound cut to 20 ms (CU2REC_BS_WAIT_S; the join
-    waits 15 x that) the launch ends by itself, the status word is set and the call reports CU2REC_EHIP -- nothing hangs.  In a
-    process of its own: both settings are read once."""
-    assert _run_fault_script(16) == "STATUS -3 True"
+    waits 15 x that) the launch ends by itself, the status word is set and the call reports CU2REC_EHIP -- nothing hangs -- and the
+    error says that the process now forks and joins with events.  It does: the SAME call on a fresh model (the signal is still never
+    sent: the event form does not need it) gives the oracle's result, and cu2rec_blocksolve_topology says "events".  In a process of
+    its own: the settings are read once."""
+    lines = _run_fault_script(16)
+    assert lines[-2] == "STATUS -3 True True", lines[-3:]
+    assert lines[-1].startswith("HEALED ") and float(lines[-1].split()[1]) <= 2e-6, lines[-1]
 
 
 def test_blocksolve_gate_that_never_opens_only_costs_time():
     """The side stream's gate kernel guards timing, not data: one that can never be satisfied (CU2REC_BS_DBG=32) gives up after the
     bound and the run goes on -- no error, and the result is the oracle's within the mode's usual rounding (a gate
     timeout must not declare the model state undefined)."""
-    last = _run_fault_script(32)
+    last = _run_fault_script(32)[-1]
     assert last.startswith("OK "), last
     assert float(last.split()[1]) <= 2e-6, last
 
@@ -530,8 +544,36 @@ for users, items, nnz, f, iters, rate, la in ((300, 120, 6000, 10, 70, 2.0, 0), 
     orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias), *state, tr.global_bias, hyper, 42, 0,
                        iters, dot_order=orc.DOT_TREE16)
     worst = max(worst, max(float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(model.download(), state)))
+print("TOPOLOGY %%s | %%s" %% api.blocksolve_topology())
 print("OK %%.3e" %% worst)
 """
+
+
+def test_blocksolve_heals_itself_when_the_streams_share_one_hardware_queue():
+    """nothing but a profiler's environment variable used to take the library off the device-side fork / join, and
+    anything else that keeps the two streams from running side by side ended in a 30 s give-up.  Now the first block-solve call probes
+    the streams it will use (a wait kernel queued first on one, a signal kernel on the other, 10 ms bound, both directions).  Here:
+    GPU_MAX_HW_QUEUES=1 in a child process -- every HIP stream of the process feeds ONE hardware queue -- and the whole small-shape
+    matrix (plain and look-ahead chains, short and long, wide rows, more chains than CUs) against the sequential oracle: the oracle's
+    results within the mode's rounding, no timeout, no error; the probe's verdict is printed, and if it says "events" the reason
+    names the probe."""
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    env.pop("CU2REC_BS_GATE", None)
+    t0 = time.time()
+    res = subprocess.run([sys.executable, "-c", _TOPOLOGY_SCRIPT % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    lines = res.stdout.strip().splitlines()
+    assert lines[-1].startswith("OK ") and float(lines[-1].split()[1]) <= 2e-6, lines[-2:]
+    assert lines[-2].startswith("TOPOLOGY "), lines[-2:]
+    mode = lines[-2].split()[1]
+    assert mode in ("events", "device"), lines[-2]
+    assert mode == "device" or "handshake probe" in lines[-2], lines[-2]
+    assert time.time() - t0 < 240, "the run took as long as a give-up would"
+    print(lines[-2])
 
 
 def test_blocksolve_event_fork_and_join_matches_sequential_oracle():
