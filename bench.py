@@ -179,6 +179,8 @@ PMC_PROFILES = {("ml-20m", 100, "blocksolve"): _latest("r[0-9][0-9]_pmc_blocksol
                 ("netflix", 128, "blocksolve"): _latest("r[0-9][0-9]_pmc_blocksolve_netflix_f128.json")}
 KERNEL_STATS = {("ml-20m", 100, "blocksolve"): _latest("r[0-9][0-9]_kernel_stats_blocksolve_ml20m_f100.csv"),
                 ("netflix", 128, "blocksolve"): _latest("r[0-9][0-9]_kernel_stats_blocksolve_netflix_f128.csv")}
+LOSS_PMC = {("ml-20m", 100): _latest("r[0-9][0-9]_pmc_loss_train_ml20m_f100.json")}
+L2_GATHER_TBS = 16.8  # MI355X_MICROARCH.md, "Indexed rows": rows shared by every workgroup (the XCD's L2), chip-wide lower bound
 # the kernels of one SGD iteration of a mode (the schedule kernels run once per batch of 64 iterations: counted per iteration below)
 ITERATION_KERNELS = {"blocksolve": ("bs_gram_kernel", "bs_solve_kernel", "bs_update_kernel", "sgd_ordered_kernel")}
 
@@ -633,10 +635,32 @@ def main():
             times.append(ev.ms(a, b))
         loss_ms = float(np.min(times))
         loss_hbm = 8 * train.nnz + 4 * f * (train.rows + train.cols) + 4 * (train.rows + train.cols) + 4 * (train.rows + 1)
+        # The pass's real bound: one Q row GATHERED per rating -- nnz x 4f bytes that the 4 MiB L2 of an XCD serves when
+        # it holds the row and the Infinity Cache when it does not (Q is 10.7 MB: it never comes from HBM twice).  Roof = the guide's
+        # measured gather rates (MI355X_MICROARCH.md, "Indexed rows": >= 16.8 TB/s from L2, 8.6 TB/s from the Infinity Cache) weighted by
+        # the L2 hit rate of the committed --pmc pass of THIS workload's train-set loss.
+        gather_bytes = 4 * f * train.nnz
+        loss_pmc = LOSS_PMC.get((args.workload, f))
+        hit = fabric = None
+        if loss_pmc and os.path.exists(os.path.join(ROOT, loss_pmc)):
+            with open(os.path.join(ROOT, loss_pmc)) as fh:
+                rec = next((v for k, v in json.load(fh).items() if "loss_fused_kernel" in k), None)
+            if rec:
+                hit, fabric = rec.get("l2_hit_rate"), rec.get("hbm_bytes_per_launch_corrected")
+        gather_roof = None if hit is None else 1.0 / (hit / L2_GATHER_TBS + (1.0 - hit) / (GATHER_PEAK_GBS / 1e3))
+        gather_tbs = gather_bytes / (loss_ms * 1e-3) / 1e12
         side["loss_kernel"] = {"kernel": "loss_fused_kernel", "ratings": train.nnz, "ms": loss_ms, "ratings_per_s": train.nnz / (loss_ms * 1e-3),
+                               "bound": "L2 / Infinity-Cache gather of one item row per rating (not HBM)",
+                               "gather_bytes": gather_bytes, "gather_TBs": gather_tbs, "l2_hit_rate": hit,
+                               "gather_roof_TBs": gather_roof, "frac_of_gather_roof": None if gather_roof is None else gather_tbs / gather_roof,
+                               "gather_roof_from": "MI355X_MICROARCH.md 'Indexed rows': %.1f TB/s (L2, lower bound) and %.1f TB/s (Infinity Cache), weighted by the "
+                                                   "L2 hit rate of %s" % (L2_GATHER_TBS, GATHER_PEAK_GBS / 1e3, loss_pmc),
                                "algorithmic_hbm_bytes": loss_hbm, "hbm_GBs": loss_hbm / (loss_ms * 1e-3) / 1e9,
                                "frac_of_hbm_peak": loss_hbm / (loss_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "note": "one call of cu2rec_loss: the fused pass, the device-side sum of its per-block partial sums and the 16-byte copy back"}
+                               "fabric_bytes_per_launch": fabric, "fabric_over_algorithmic_hbm": None if fabric is None else fabric / loss_hbm,
+                               "fabric_note": "FETCH_SIZE (doubled) + WRITE_SIZE count what leaves L2 for the fabric: item rows re-fetched past the 4 MiB L2 are "
+                                              "served by the 256 MB Infinity Cache, not by HBM, so this is NOT wasted HBM traffic -- it is the miss side of the gather",
+                               "note": "one call of cu2rec_loss on the train set: the fused pass, the device-side sum of its per-block partial sums and the 16-byte copy back"}
 
     if rank == 0:
         traffic, traffic_src = profile_traffic(args.workload, f, mode)

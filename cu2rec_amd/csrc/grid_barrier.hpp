@@ -1,5 +1,5 @@
-// The grid-wide barrier of the persistent launches (resident.hip: Hogwild with the user rows in registers; ordered.hip: the
-// ordered walk of a small set, all iterations of a batch in one launch): XCD-hierarchical, split in two halves, every spin bounded.
+// The grid-wide barrier of the persistent launches (resident.hip: Hogwild with the user rows in registers -- the one persistent
+// launch left: the ordered walk's was removed in round 5): XCD-hierarchical, split in two halves, every spin bounded.
 // MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility" ("barrier-xcd").  The functions take any
 // argument block with .words (the barrier block below, zeroed before the launch) and .status (set by a wait that gave up).
 #pragma once

@@ -725,7 +725,12 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
         // iteration a threshold of 60 still pays a little (an eighth of the ML-20M shape, hottest item 247: 32.5 us per iteration
         // against 35.3 walking everything; thresholds 40 / 60 / 90 / 130 / 180: 32.6 / 32.5 / 33.7 / 37.5 / 41.4, round 5); below
         // that no chain is long enough to pay for three launches per iteration and the mode IS the ordered walk (ML-1M shape)
-        if (n_cols > 0 && rate[order[0]] < 350.0) min_rate = rate[order[0]] >= 150.0 ? 60.f : std::numeric_limits<float>::infinity();
+        // Only for SMALL sets (at most a quarter of 131,072 users: where the rule was measured).  A large set with flat popularity --
+        // many users, hottest item under 350 -- keeps the scaled threshold: there "every item above 60" would be hundreds of
+        // 512-thread solve workgroups the side stream's gate has to see started (the regime that did not fit the CUs on the
+        // Netflix shape), and nothing was measured there.
+        if (n_cols > 0 && n_active <= 131072 / 4 && rate[order[0]] < 350.0)
+            min_rate = rate[order[0]] >= 150.0 ? 60.f : std::numeric_limits<float>::infinity();
     }
     n_hot_bs = 0;
     while (n_hot_bs < n_cols && rate[order[n_hot_bs]] >= min_rate) ++n_hot_bs;

@@ -532,8 +532,8 @@ void resident_check_fault() {
         *s.host_status = 0;
         fail(CU2REC_EHIP,
              "cu2rec_amd: a persistent SGD launch gave up at its grid barrier (the grid was not co-resident: is another "
-             "process or stream using this GPU?); the model state is undefined.  CU2REC_RESIDENT=0 (Hogwild) / "
-             "CU2REC_ORDERED_PERSISTENT=0 (ordered mode, small sets) select the one-launch-per-iteration kernels");
+             "process or stream using this GPU?); the model state is undefined.  cu2rec_hogwild_resident(0) / "
+             "CU2REC_RESIDENT=0 selects the one-launch-per-iteration Hogwild kernel");
     }
 }
 

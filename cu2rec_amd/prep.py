@@ -8,6 +8,8 @@ int(n * (1 - test_ratio)) of them for training, both halves stably sorted by use
   python -m cu2rec_amd.prep map    ratings.csv            -> ratings_mapped.csv   (preprocessing/map_items.py:21-89)
   python -m cu2rec_amd.prep split  ratings_mapped.csv     -> *_train.csv, *_test.csv (split_to_test_train.py:39-78)
   python -m cu2rec_amd.prep config out.cfg [--iters ...]  -> 9-field config       (create_config.py:10-32)
+  python -m cu2rec_amd.prep sort   ratings.csv            -> ratings_sorted.csv   (sort_ratings.py:11-42: by (userId, itemId))
+  python -m cu2rec_amd.prep to-npy p.csv [q.csv ...]      -> p.npy ...            (convert_to_np.py:6-23: float64 .npy)
   python -m cu2rec_amd.prep map-netflix train.txt test.txt -> ratings_mapped_train.csv, ratings_mapped_test.csv next to train.txt
                                                                                   (map_netflix.py:9-28)
 """
@@ -58,6 +60,23 @@ def map_ids(src, dst=None):
     dst = dst or os.path.splitext(src)[0] + "_mapped.csv"
     _write(dst, user[order], item[order], rating[order])
     return dst, int(user.max(initial=0)), int(item.max(initial=0)), len(user)
+
+
+def sort_ratings(src, dst=None):
+    """sort_ratings.py:11-42: rows ordered by (userId, itemId), ids left as they are, stable; -> <name>_sorted<ext>."""
+    user, item, rating = _read_triples(src)
+    order = np.lexsort((item, user))  # (stable: rows equal in both keys keep their file order, like sorted())
+    base, ext = os.path.splitext(src)
+    dst = dst or base + "_sorted" + ext
+    _write(dst, user[order], item[order], rating[order])
+    return dst
+
+
+def to_npy(src, dst=None):
+    """convert_to_np.py:6-14: a CSV of floats (the trainer's p / q / bias files) as a float64 .npy next to it."""
+    dst = dst or os.path.splitext(src)[0] + ".npy"
+    np.save(dst, np.genfromtxt(src, delimiter=","))
+    return dst
 
 
 def _read_netflix(path):
@@ -154,6 +173,11 @@ def main(argv=None):
     s.add_argument("--test-fraction", type=float, default=0.2)
     s.add_argument("--seed", type=int, default=42)
     s.add_argument("--keep-users", action="store_true", help="every user keeps at least one training rating (not the reference's behaviour)")
+    so = sub.add_parser("sort")
+    so.add_argument("src")
+    so.add_argument("dst", nargs="?")
+    tn = sub.add_parser("to-npy")
+    tn.add_argument("files", nargs="+")
     nf = sub.add_parser("map-netflix")
     nf.add_argument("train")
     nf.add_argument("test")
@@ -167,6 +191,10 @@ def main(argv=None):
     args = ap.parse_args(argv)
     if args.cmd == "map":
         print("%s: %d users, %d items, %d ratings" % map_ids(args.src, args.dst))
+    elif args.cmd == "sort":
+        print(sort_ratings(args.src, args.dst))
+    elif args.cmd == "to-npy":
+        print(" ".join(to_npy(f) for f in args.files))
     elif args.cmd == "map-netflix":
         print("%s %s" % map_netflix(args.train, args.test))
     elif args.cmd == "split":

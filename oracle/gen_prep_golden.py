@@ -10,6 +10,9 @@ child processes, on a small raw file this script makes up; only their OUTPUTS ar
   prep_ref_train.csv      preprocessing/split_to_test_train.py prep_ref_mapped.csv 0.2   (random.seed(42) shuffle, first 80 %,
   prep_ref_test.csv         both halves stably sorted by user)
   prep_ref_config.cfg     preprocessing/create_config.py -n 500 -f 50 -l 0.005 -s 7 -p 0.03 -q 0.04 -u 0.05 -i 0.06
+  prep_ref_sorted.csv     preprocessing/sort_ratings.py prep_raw.csv           (rows sorted by (userId, itemId), ids as they are)
+  prep_matrix.csv         a made-up 5 x 4 float matrix in the trainer's `%f` output format (util.cu:86-97), and
+  prep_ref_matrix.npy       preprocessing/convert_to_np.py prep_matrix.csv     (np.genfromtxt -> np.save: float64)
   prep_netflix_train.txt  made-up raw Netflix split files (`user item  rating`, no header; the test file names two users and an item
   prep_netflix_test.txt     the training file does not)
   prep_ref_netflix_train.csv, prep_ref_netflix_test.csv   preprocessing/map_netflix.py on those (run where its hard-wired relative
@@ -78,6 +81,15 @@ def main():
         run(os.path.join(REF, "split_to_test_train.py"), mapped, "0.2")                    # -> *_train.csv, *_test.csv
         run(os.path.join(REF, "create_config.py"), os.path.join(tmp, "c.cfg"), "-n", "500", "-f", "50", "-l", "0.005", "-s", "7",
             "-p", "0.03", "-q", "0.04", "-u", "0.05", "-i", "0.06")
+        run(os.path.join(REF, "sort_ratings.py"), raw)                                     # -> prep_raw_sorted.csv
+        rng = np.random.RandomState(20241006)
+        with open(os.path.join(tmp, "prep_matrix.csv"), "w") as fh:
+            for row in rng.normal(0, 0.3, (5, 4)):
+                fh.write(",".join("%f" % v for v in row) + "\n")
+        run(os.path.join(REF, "convert_to_np.py"), os.path.join(tmp, "prep_matrix.csv"))   # -> prep_matrix.npy
+        for src, dst in (("prep_raw_sorted.csv", "prep_ref_sorted.csv"), ("prep_matrix.csv", "prep_matrix.csv"), ("prep_matrix.npy", "prep_ref_matrix.npy")):
+            shutil.copyfile(os.path.join(tmp, src), os.path.join(GOLD, dst))
+            print("wrote tests/golden/" + dst)
         for src, dst in (("prep_raw.csv", "prep_raw.csv"), ("prep_raw_mapped.csv", "prep_ref_mapped.csv"),
                          ("prep_raw_mapped_train.csv", "prep_ref_train.csv"), ("prep_raw_mapped_test.csv", "prep_ref_test.csv"),
                          ("c.cfg", "prep_ref_config.cfg")):
