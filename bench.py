@@ -185,6 +185,22 @@ L2_GATHER_TBS = 16.8  # MI355X_MICROARCH.md, "Indexed rows": rows shared by ever
 ITERATION_KERNELS = {"blocksolve": ("bs_gram_kernel", "bs_solve_kernel", "bs_update_kernel", "sgd_ordered_kernel")}
 
 
+def profile_provenance(files):
+    """Do the committed profile files belong to THIS build?  profiles/rNN_profile_meta.json (tools/source_digest.py --write) records the
+    kernel sources' digest the round's summaries were taken from; a summary of another build beside a live timing is a mixed roofline."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_digest import kernel_source_digest
+    now, meta_file = kernel_source_digest(), _latest("r[0-9][0-9]_profile_meta.json")
+    out = {"build_source_digest": now, "profile_meta": meta_file, "profile_source_digest": None, "profiles_match_build": None}
+    if meta_file:
+        with open(os.path.join(ROOT, meta_file)) as fh:
+            meta = json.load(fh)
+        covered = all(os.path.basename(f) in meta.get("covers", []) for f in files if f)
+        out["profile_source_digest"] = meta.get("source_digest") if covered else None
+        out["profiles_match_build"] = bool(covered and meta.get("source_digest") == now)
+    return out
+
+
 def profile_traffic(workload, factors, mode):
     """HBM-side bytes per iteration from the committed PMC summary of this workload (FETCH_SIZE doubled per
     MI355X_MICROARCH.md; separate --pmc passes), or (None, why): the sum over the iteration's kernels of their corrected
@@ -699,6 +715,7 @@ def main():
                              "traffic_profile": "EVENT topology: a rocprofv3 --pmc pass serialises kernels across streams, so the library forks / joins the "
                                                 "side stream with events there (same kernels, same bytes; the pass is for counters, never for timing)"},
                          "kernels": profile_kernels(args.workload, f, mode),
+                         "profile_provenance": profile_provenance([PMC_PROFILES.get((args.workload, f, mode)), KERNEL_STATS.get((args.workload, f, mode))]),
                          "kernel": kernels.get(mode, mode), "bytes_per_update": bytes_per_update,
                          "algorithmic_bytes": alg_bytes, "device_seconds": elapsed_dev,
                          "note": "algorithmic bytes of the timed region (rank 0's updates x (16 f + 32)) / its duration by HIP events on "

@@ -290,6 +290,46 @@ __device__ __forceinline__ void store_wide_row(float *__restrict__ base, size_t 
     }
 }
 
+#ifndef CU2REC_WALK_NT
+#define CU2REC_WALK_NT 0  // tuning builds (tools/build_variant.sh): 1 user rows of the chains' kernel STORED non-temporally, 2 loaded so, 3 both
+#endif
+// a user row is written once per iteration and not read again before the next one: the streaming form keeps it from displacing item
+// rows in the XCD's L2 (measured on the Netflix shape in round 6: profiles/r06_netflix_walk_experiments.txt)
+template <int W, int S>
+__device__ __forceinline__ void store_user_wide_row(float *__restrict__ base, size_t row, int ld, int nslots, int lane, const WideRow<S> &r) {
+#if CU2REC_WALK_NT & 1
+    float4 *p = reinterpret_cast<float4 *>(base + row * static_cast<size_t>(ld));
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int slot = lane + W * s;
+        if (slot < nslots) {
+            const vec4f v = {r.v[s].x, r.v[s].y, r.v[s].z, r.v[s].w};
+            __builtin_nontemporal_store(v, reinterpret_cast<vec4f *>(&p[slot]));
+        }
+    }
+#else
+    store_wide_row<W, S>(base, row, ld, nslots, lane, r);
+#endif
+}
+
+template <int J>
+__device__ __forceinline__ void store_user_row(float *__restrict__ base, size_t row, int ld, int nslots, int lane, const Row<J> &r) {
+#if CU2REC_WALK_NT & 1
+    store_row_stream<J>(base, row, ld, nslots, lane, r);
+#else
+    store_row<J>(base, row, ld, nslots, lane, r);
+#endif
+}
+
+template <int J>
+__device__ __forceinline__ Row<J> load_user_row(const float *__restrict__ base, size_t row, int ld, int nslots, int lane) {
+#if CU2REC_WALK_NT & 2
+    return load_row_stream<J>(base, row, ld, nslots, lane);
+#else
+    return load_row<J>(base, row, ld, nslots, lane);
+#endif
+}
+
 // this wave's entries of the tile starting at tile_start, one per lane 0..part-1 (mirrored on the other lanes)
 template <int W, int S>
 __device__ __forceinline__ uint64_t duo_load_vals(const uint64_t *__restrict__ vals, int tile_start, int end, int part,
@@ -344,7 +384,7 @@ __device__ __forceinline__ void duo_update_users(DuoLds<W, S> &l, int buf, int n
                 pn.v[s].z = step(po.z, qo.z, err, a.h.lr, a.h.p_reg);
                 pn.v[s].w = step(po.w, qo.w, err, a.h.lr, a.h.p_reg);
             }
-            store_wide_row<W, S>(a.P, static_cast<size_t>(l.user[buf][e]), a.ldp, a.nslots, lane, pn);
+            store_user_wide_row<W, S>(a.P, static_cast<size_t>(l.user[buf][e]), a.ldp, a.nslots, lane, pn);
         }
     }
     const int mine = kPart * part + lane;
@@ -545,7 +585,7 @@ __device__ __forceinline__ void walk_group(const SgdArgs &a, const uint32_t *__r
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int x = static_cast<int>(link(mv, d, nw) >> 32);
-            cur[d] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+            cur[d] = load_user_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
             cub[d] = a.user_bias[x];
         }
     };
@@ -572,7 +612,7 @@ __device__ __forceinline__ void walk_group(const SgdArgs &a, const uint32_t *__r
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int x = static_cast<int>(link(myval, b0 + D + d, nw) >> 32);
-                nxt[d] = load_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
+                nxt[d] = load_user_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane);
                 nub[d] = a.user_bias[x];
             }
 #pragma unroll
@@ -581,7 +621,7 @@ __device__ __forceinline__ void walk_group(const SgdArgs &a, const uint32_t *__r
                     const uint64_t val = link(myval, b0 + d, nw);
                     const int x = static_cast<int>(val >> 32);
                     const float new_ub = chain_step<J>(a, cur[d], q, cub[d], ib, __uint_as_float(static_cast<uint32_t>(val)));
-                    store_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, cur[d]);
+                    store_user_row<J>(a.P, static_cast<size_t>(x), a.ldp, a.nslots, lane, cur[d]);
                     if (lane == 0) a.user_bias[x] = new_ub;
                 }
             }
@@ -1035,12 +1075,22 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                     if (!(dbg & 16)) bs_launch_signal(side_seq.ptr, side_seq_host, upd);
                     bs_launch_update(a, it, stream);
                 } else {
+                    // (test build, TIMING ONLY, results wrong: 64 the side kernel alone, 128 the three phases alone -- what each path costs
+                    // on an otherwise idle chip, tools/path_isolation.sh)
                     if (upd_pending) CU2REC_HIP(hipStreamWaitEvent(stream, ev_upd, 0));  // join: rows the next phase 1 reads
-                    bs_launch_gram(a, it, stream, ev_gram);
-                    CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
-                    bs_launch_solve(a, it, stream);
-                    launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, ranges, ev_upd);
-                    bs_launch_update(a, it, stream);
+                    if (!(dbg & 64)) {
+                        bs_launch_gram(a, it, stream, ev_gram);
+                        CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
+                        bs_launch_solve(a, it, stream);
+                    } else {
+                        CU2REC_HIP(hipEventRecord(ev_gram, stream));
+                        CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
+                    }
+                    if (!(dbg & 128))
+                        launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, ranges, ev_upd);
+                    else
+                        CU2REC_HIP(hipEventRecord(ev_upd, upd));
+                    if (!(dbg & 64)) bs_launch_update(a, it, stream);
                     upd_pending = true;
                 }
             }
