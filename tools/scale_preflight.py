@@ -16,7 +16,7 @@
      bench.py --gpus N --steps 20 --warmup 5` -- as a fresh child in its own process group under a watchdog (--bench-timeout
      seconds: the whole group is killed and the tool exits non-zero), and checks the JSON line: n_gpus == N, steps / warmup as asked,
      what RCCL itself reports (rccl.rccl_nranks == N for N > 1), one per_rank record per rank, at least one timed region with an
-     exchange.  --bench-args appends flags (tests: a small workload).
+     exchange.  --bench-args="..." appends flags (tests: a small workload; write it with the equals sign when the value starts with --).
 Prints one PASS / FAIL line per step; exit code 0 only if all passed.  The bench line is echoed, but no number of this tool is a result."""
 import argparse
 import hashlib
