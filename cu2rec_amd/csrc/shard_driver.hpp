@@ -111,7 +111,12 @@ struct ShardDriver {
                 // target, and all shards' updates in sequence would make phi of the total -- alpha is 1 for an item that is
                 // rarely updated (the sum is what the sequential run does) and 1 / N for an item every shard updates many times
                 // per iteration (the mean).  c = 6 fitted on the ML-20M shape (tools/shard_study.py, profiles/r02_shard_study_*).
-                double c = 6.0;
+                // ... and scaled with the exchange period (round 6): what saturates an item row is its updates per PERIOD, so a run
+                // that exchanges every sync_every iterations instead of once per epoch uses c = 6 sync_every / epoch (N = 8, converged,
+                // equal LR histories: sync 2 -3.0e-3 instead of -1.1e-2, sync 1 -1.5e-3; profiles/r06_sharded_equal_schedule.txt).  At
+                // the default period -- one epoch -- nothing changes.
+                const double epoch = std::max(1.0, nnz_total / std::max(users_total, 1.0));
+                double c = 6.0 * std::min(1.0, static_cast<double>(sync_every) / epoch);
                 if (const char *env = std::getenv("CU2REC_MERGE_ADAPTIVE_C")) c = std::max(1e-3, std::atof(env));
                 std::vector<double> phi(rate.size());
                 for (size_t y = 0; y < rate.size(); ++y) phi[y] = -std::expm1(-c * rate[y]);

@@ -478,10 +478,11 @@ typedef enum cu2rec_merge {
     CU2REC_MERGE_MEAN = 0,     /* scale 1 / nranks */
     CU2REC_MERGE_WEIGHTED = 1, /* per item: w_k[y] = rank k's share of the item's expected updates per iteration */
     CU2REC_MERGE_SUM = 2,      /* scale 1: diverges when many ranks update the same items many times per period */
-    CU2REC_MERGE_ADAPTIVE = 3  /* the sum, scaled per item by phi(r_total) / sum_k phi(r_k), phi(r) = 1 - exp(-6 r), r = expected
-                                * updates of the item per iteration: the sum for rarely updated items, the mean for items every rank
-                                * updates all the time.  ML-20M shape, 8 shards, 1,000 iterations: test RMSE 3e-4 from the unsharded
-                                * sequential result (mean / weighted: 1e-3) */
+    CU2REC_MERGE_ADAPTIVE = 3  /* the sum, scaled per item by phi(r_total) / sum_k phi(r_k), phi(r) = 1 - exp(-c r), r = expected
+                                * updates of the item per iteration, c = 6 * min(1, sync_every / epoch) (what saturates a row is its
+                                * updates per PERIOD; CU2REC_MERGE_ADAPTIVE_C overrides c): the sum for rarely updated items, the mean
+                                * for items every rank updates all the time.  ML-20M shape, 8 shards, 1,000 iterations: test RMSE 3e-4
+                                * from the unsharded sequential result (mean / weighted: 1e-3) */
 } cu2rec_merge;
 typedef struct cu2rec_shard_options {
     int sync_every; /* iterations between exchanges; 0 = one epoch = round(nnz / users) of the whole population */

@@ -130,9 +130,10 @@ def test_two_ranks_one_gpu_cpp_driver_matches_oracle(tmp_path, merge):
         tot = rates[0] + rates[1]
         w = [np.where(tot > 0, rk / np.where(tot > 0, tot, 1), 0.5).astype(np.float32) for rk in rates]
         scale = np.float32(1.0)
-    elif merge == "adaptive":  # the sum, scaled per item by phi(r_total) / sum_k phi(r_k), phi(r) = 1 - exp(-6 r)
+    elif merge == "adaptive":  # the sum, scaled per item by phi(r_total) / sum_k phi(r_k), phi(r) = 1 - exp(-c r), c = 6 sync / epoch
         rates = [cu.api.item_update_rates(tr.slice_users(u0, u1)).astype(np.float64) for u0, u1 in bounds]
-        phi = lambda r: -np.expm1(-6.0 * r)
+        c = 6.0 * min(1.0, sync / max(1.0, tr.nnz / max(np.count_nonzero(np.diff(tr.indptr)), 1)))
+        phi = lambda r: -np.expm1(-c * r)
         den = phi(rates[0]) + phi(rates[1])
         alpha = np.where(den > 0, phi(rates[0] + rates[1]) / np.where(den > 0, den, 1), 1.0).astype(np.float32)
         w = [alpha, alpha]

@@ -130,8 +130,10 @@ def _emulate(tr, f, world, sync, iters, merge):
     if merge == "weighted":
         w = [np.where(tot > 0, r / np.maximum(tot, 1e-300), 1.0 / world).astype(np.float32) for r in rates]
     elif merge == "adaptive":
-        phi = -np.expm1(-6.0 * rates)
-        alpha = np.where(phi.sum(0) > 0, -np.expm1(-6.0 * tot) / np.maximum(phi.sum(0), 1e-300), 1.0).astype(np.float32)
+        # c = 6 scaled with the exchange period: sync / epoch, epoch = nnz / users with ratings (shard_driver.hpp)
+        c = 6.0 * min(1.0, sync / max(1.0, tr.nnz / max(np.count_nonzero(np.diff(tr.indptr)), 1)))
+        phi = -np.expm1(-c * rates)
+        alpha = np.where(phi.sum(0) > 0, -np.expm1(-c * tot) / np.maximum(phi.sum(0), 1e-300), 1.0).astype(np.float32)
         w = [alpha] * world
     else:
         w = [None] * world
