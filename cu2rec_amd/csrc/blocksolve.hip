@@ -324,30 +324,9 @@ __device__ __forceinline__ void gram_cross_block(const SgdArgs &a, const BsItera
 constexpr int kGramTabFloats = 2 * kB;  // a^d | c^d, d in [0, 64)
 __host__ __device__ inline size_t gram_tile_float4s(int nslots) { return static_cast<size_t>(kB) * (nslots | 1); }
 
-__global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration it) {
-    extern __shared__ float4 bs_smem[];
+// One block of phase 1 (the body of bs_gram_kernel): its rows -> LDS, the Gram tiles, (I + N)^-1, the record.  Workgroup uniform.
+__device__ __forceinline__ void gram_block(const SgdArgs &a, const BsIteration &it, int g, float4 *bs_smem, WaveStamp &stamp) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = static_cast<int>(blockIdx.x) - it.la_grid;  // (the first la_grid workgroups of the launch: the cross blocks)
-    __builtin_amdgcn_s_setprio(2);  // (above the walk beside us and the schedule's kernels: this launch is on the iteration's critical path)
-    WaveStamp stamp(it);
-    // (every workgroup counts itself through, used or not: the side stream's gate waits for the whole grid)
-    struct Through {
-        unsigned long long *count;
-        __device__ ~Through() {
-            // 32 shards, 128 bytes apart: two thousand atomics on ONE word took longer than phase 1 itself
-            if (count && threadIdx.x == 0)
-                __hip_atomic_fetch_add(count + 16 * (blockIdx.x & 31), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    } through_count{it.gram_done};
-    if (g < 0) {
-        // the cross blocks of the look-ahead chains, whose blocks are the first of the table; dispatched first: they have nothing to
-        // wait for and end long before the inversions do
-        const BsChainDesc last = it.chains[it.la_ranks - 1];
-        const int la_end = min(last.blk0 + (last.len + kB - 1) / kB, it.la_cap);
-        for (int gb = g + it.la_grid; gb < la_end; gb += it.la_grid) gram_cross_block(a, it, gb, bs_smem);
-        stamp.done(it, 7, 4 * (g + it.la_grid) + wave);
-        return;
-    }
     const BsBlockDesc bd = it.blocks[g];
     if (bd.n_valid == 0) return;  // (the grid is an upper bound of the iteration's blocks)
     const int nslots = a.nslots, RS = nslots | 1;
@@ -525,6 +504,38 @@ __global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration 
         if (t < kB / 4) *reinterpret_cast<f32x4 *>(rec + kBsFactorFloats + 4 * t) = *reinterpret_cast<const f32x4 *>(basev + 4 * t);
     }
     stamp.done(it, 1, 4 * g + wave);
+}
+
+__global__ __launch_bounds__(256, 4) void bs_gram_kernel(SgdArgs a, BsIteration it) {
+    extern __shared__ float4 bs_smem[];
+    const int wave = threadIdx.x >> 6;
+    const int g = static_cast<int>(blockIdx.x) - it.la_grid;  // (the first la_grid workgroups of the launch: the cross blocks)
+    __builtin_amdgcn_s_setprio(2);  // (above the walk beside us and the schedule's kernels: this launch is on the iteration's critical path)
+    WaveStamp stamp(it);
+    // (every workgroup counts itself through, used or not: the side stream's gate waits for the whole grid)
+    struct Through {
+        unsigned long long *count;
+        __device__ ~Through() {
+            // 32 shards, 128 bytes apart: two thousand atomics on ONE word took longer than phase 1 itself
+            if (count && threadIdx.x == 0)
+                __hip_atomic_fetch_add(count + 16 * (blockIdx.x & 31), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } through_count{it.gram_done};
+    if (g < 0) {
+        // the cross blocks of the look-ahead chains, whose blocks are the first of the table; dispatched first: they have nothing to
+        // wait for and end long before the inversions do
+        const BsChainDesc last = it.chains[it.la_ranks - 1];
+        const int la_end = min(last.blk0 + (last.len + kB - 1) / kB, it.la_cap);
+        for (int gb = g + it.la_grid; gb < la_end; gb += it.la_grid) gram_cross_block(a, it, gb, bs_smem);
+        stamp.done(it, 7, 4 * (g + it.la_grid) + wave);
+        return;
+    }
+    // (one workgroup per slot of the block table, max_blocks of them -- the worst case; most find their descriptor empty and leave.  Launching
+    // only as many as an iteration is expected to fill needs a way to do the rest when an iteration has more: as a stride loop around
+    // gram_block it cost this kernel 55 spilled registers, as an out-of-line function a scratch frame -- 92 instead of 79 us per
+    // iteration on the ML-20M shape either way (round 6, profiles/r06_launch_bounds.txt).  Phase 3 and the walk, whose kernels have the
+    // registers to spare, do stride: bs_update_kernel, sgd_ordered_kernel.)
+    gram_block(a, it, g, bs_smem, stamp);
 }
 
 // ---- phase 2: the chains ----------------------------------------------------------------------------------------------
@@ -1406,11 +1417,15 @@ __global__ __launch_bounds__(64 * kUpdMaxWaves) void bs_update_kernel(SgdArgs a,
     const int g = blockIdx.x;
     WaveStamp stamp(it);
     __builtin_amdgcn_s_setprio(2);
-    if (g == it.max_blocks) {  // the extra workgroup of the launch (side_seq set)
+    if (g == it.launch_blocks) {  // the extra workgroup of the launch (side_seq set)
         if (threadIdx.x == 0) await_iteration_end(it);
         return;
     }
-    update_block(a, it, g, nwaves, stamp);
+    // (launch_blocks workgroups stride through the dense block table, like phase 1's; update_block keeps nothing in LDS)
+    for (int blk = g; blk < it.max_blocks; blk += it.launch_blocks) {
+        if (it.blocks[blk].n_valid == 0) break;  // workgroup uniform
+        update_block(a, it, blk, nwaves, stamp);
+    }
 }
 
 template <int SW>
@@ -1728,7 +1743,7 @@ void bs_launch_solve(const SgdArgs &a, const BsIteration &it, hipStream_t stream
 void bs_launch_update(const SgdArgs &a, const BsIteration &it, hipStream_t stream) {
     if (it.n_hot <= 0 || it.max_blocks <= 0) return;
     const int nwaves = (4 * a.nslots + 63) / 64;
-    hipLaunchKernelGGL(bs_update_kernel, dim3(it.max_blocks + (it.side_seq ? 1 : 0)), dim3(64 * nwaves), 0, stream, a, it, nwaves);
+    hipLaunchKernelGGL(bs_update_kernel, dim3(it.launch_blocks + (it.side_seq ? 1 : 0)), dim3(64 * nwaves), 0, stream, a, it, nwaves);
     CU2REC_HIP(hipGetLastError());
 }
 

@@ -51,6 +51,10 @@ struct BsIteration {
     float *ebuf;              // [max_blocks][kBsLinks]      error of each hot link
     float *qstart;            // [max_blocks][ldq]           item row at the start of each block
     int max_blocks;
+    // workgroups phase 3 is LAUNCHED with (<= max_blocks; phase 1 keeps the full grid: blocksolve.hip): what an iteration is expected to have, mean + 8 sigma of the hot links
+    // (OrderedSchedule::blocks_bound); the block table is dense and the workgroups stride through it, so a busier iteration is still
+    // done completely
+    int launch_blocks;
     // Look-ahead chains (blocksolve.hip, "look-ahead form"): popularity ranks [0, la_ranks) -- the long chains, whose length IS the
     // iteration's critical path.  Phase 1 also builds the block of lr L that couples each of their blocks to the one before it
     // (la_grid more workgroups in its launch), and phase 2 runs them with the item row OFF the dependent path.

@@ -645,7 +645,8 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
                                                              const uint64_t *__restrict__ vals, int n_active,
                                                              const int *__restrict__ item_of_rank,
                                                              uint32_t item_mask, int n_hot,
-                                                             int hot_blocks, int rank_lo, const int *__restrict__ ranges) {
+                                                             int hot_blocks, int rank_lo, const int *__restrict__ ranges,
+                                                             int walk_lo, int walk_blocks) {
     // above the schedule's kernels (priority 0), which run BESIDE the iterations: where a wavefront of theirs shares a SIMD with one
     // of an iteration's, the iteration's goes first (a kernel ends with its slowest workgroup: profiles/r05_handwritten_sort_experiment.txt)
     __builtin_amdgcn_s_setprio(1);
@@ -654,38 +655,52 @@ __global__ __launch_bounds__(kBlock) void sgd_ordered_kernel(SgdArgs a, const ui
         run_hot_block_duo<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>(a, keys, vals, n_active, n_hot, item_of_rank, rank_lo, ranges);
         return;
     }
-    walk_group<J>(a, keys, vals, n_active, item_of_rank, item_mask, n_hot,
-                  static_cast<int>((blockIdx.x - hot_blocks) * kBlock + threadIdx.x) / kGroup);
+    // The walk: one 16-lane group per sorted position of [walk_lo, n_active) -- the tail of the sorted iteration, where the chains of
+    // the unpopular items are (OrderedSchedule::walk_bound: the host knows how long that tail is, give or take a few hundred positions;
+    // the positions in front of it belong to two-wave chains and used to cost a workgroup each just to find that out: 84 % of the walk's
+    // workgroups on the Netflix shape).  One extra workgroup sweeps whatever walked chains an iteration has in FRONT of walk_lo.
+    const int wb = static_cast<int>(blockIdx.x) - hot_blocks;
+    if (wb < walk_blocks) {
+        walk_group<J>(a, keys, vals, n_active, item_of_rank, item_mask, n_hot, walk_lo + (wb * kBlock + static_cast<int>(threadIdx.x)) / kGroup);
+        return;
+    }
+    const int sweep_lo = ranges[n_hot];  // first sorted position whose rank is >= n_hot (chain_ranges_kernel)
+    for (int p = sweep_lo + static_cast<int>(threadIdx.x) / kGroup; p < walk_lo; p += kGroupsPerBlock)
+        walk_group<J>(a, keys, vals, n_active, item_of_rank, item_mask, n_hot, p);
 }
 
 // One iteration's chains of ranks >= rank_lo: the two-wave chains of ranks [rank_lo, n_hot) and the walk of the rest, one launch.
 template <int J>
 void launch_chain(const SgdArgs &a, const uint32_t *keys, const uint64_t *vals, int n_active, const int *item_of_rank,
-                  uint32_t item_mask, int n_hot, hipStream_t stream, int rank_lo, const int *ranges, hipEvent_t stop) {
+                  uint32_t item_mask, int n_hot, hipStream_t stream, int rank_lo, const int *ranges, hipEvent_t stop, int walk_bound) {
     const int chains_per_block = DuoShape<(J == 2 ? kWide : kGroup), (J == 2 ? 1 : J)>::kChains;
     const int hot_blocks = (std::max(n_hot - rank_lo, 0) + chains_per_block - 1) / chains_per_block;
-    const int walk_blocks = (n_active + kGroupsPerBlock - 1) / kGroupsPerBlock;
-    const int blocks = hot_blocks + walk_blocks;
+    // the walk covers the last walk_bound positions (whole workgroups); with the chains' ranges at hand one more workgroup sweeps what an
+    // iteration may have in front of them (see the kernel); without them (ranges == nullptr) the walk covers every position
+    int walk_lo = 0;
+    if (ranges && walk_bound < n_active) walk_lo = ((n_active - walk_bound) / kGroupsPerBlock) * kGroupsPerBlock;
+    const int walk_blocks = (n_active - walk_lo + kGroupsPerBlock - 1) / kGroupsPerBlock;
+    const int blocks = hot_blocks + walk_blocks + (walk_lo > 0 ? 1 : 0);
     if (blocks == 0) return;
     if (stop)  // the event rides on the kernel's completion signal (see bs_launch_gram)
         hipExtLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, nullptr, stop, 0, a, keys, vals, n_active,
-                              item_of_rank, item_mask, n_hot, hot_blocks, rank_lo, ranges);
+                              item_of_rank, item_mask, n_hot, hot_blocks, rank_lo, ranges, walk_lo, walk_blocks);
     else
         hipLaunchKernelGGL(sgd_ordered_kernel<J>, dim3(blocks), dim3(kBlock), 0, stream, a, keys, vals, n_active,
-                           item_of_rank, item_mask, n_hot, hot_blocks, rank_lo, ranges);
+                           item_of_rank, item_mask, n_hot, hot_blocks, rank_lo, ranges, walk_lo, walk_blocks);
 }
 
 void launch_chains(const SgdArgs &a, const uint32_t *kb, const uint64_t *vb, int n_active, const int *item_of_rank,
-                   uint32_t item_mask, int n_hot, hipStream_t stream, int rank_lo, const int *ranges = nullptr, hipEvent_t stop = nullptr) {
+                   uint32_t item_mask, int n_hot, hipStream_t stream, int rank_lo, const int *ranges, hipEvent_t stop, int walk_bound) {
     switch (slots_per_lane(a.nslots)) {
-        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
-        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
-        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
-        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
-        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
-        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
-        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
-        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop); break;
+        case 1: launch_chain<1>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop, walk_bound); break;
+        case 2: launch_chain<2>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop, walk_bound); break;
+        case 3: launch_chain<3>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop, walk_bound); break;
+        case 4: launch_chain<4>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop, walk_bound); break;
+        case 5: launch_chain<5>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop, walk_bound); break;
+        case 6: launch_chain<6>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop, walk_bound); break;
+        case 7: launch_chain<7>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop, walk_bound); break;
+        case 8: launch_chain<8>(a, kb, vb, n_active, item_of_rank, item_mask, n_hot, stream, rank_lo, ranges, stop, walk_bound); break;
         default: fail(CU2REC_EUNSUPPORTED, "n_factors above 512 is not compiled in");
     }
 }
@@ -729,6 +744,8 @@ OrderedSchedule::OrderedSchedule(const int *d_indptr, const int *d_indices, int 
     item_rank.upload(rank.data(), n_cols);
     item_of_rank.allocate(n_cols);
     item_of_rank.upload(order.data(), n_cols);
+    rank_rate_prefix.assign(static_cast<size_t>(n_cols) + 1, 0.0);
+    for (int r = 0; r < n_cols; ++r) rank_rate_prefix[r + 1] = rank_rate_prefix[r] + rate[order[r]];
     item_bits = bits_for(n_cols);
     // batch size: keep key = b << item_bits | rank (+ the sentinel bit) inside 32 bits and the buffers modest
     int b_bits = std::min(6, 31 - item_bits - 1);
@@ -893,6 +910,35 @@ float blocksolve_min_rate(float rate) {
     return prev > 0.f ? prev : -1.f;
 }
 
+// How many sorted positions the walk behind popularity rank n_hot has to cover in one iteration, as an upper bound that holds in all but
+// astronomically rare iterations: a user lands behind rank n_hot with probability 1 - (its ratings of the n_hot most popular items) / (its
+// ratings), independently; the count's mean is n_active - rank_rate_prefix[n_hot] and its variance at most that mean.  Mean + 8 sigma + 64.
+// The launch covers exactly that many positions at the END of the sorted iteration (where the unpopular items' chains are); whatever an
+// iteration has beyond it is swept by one extra workgroup (sgd_ordered_kernel), so the bound is about speed, never about results.
+int OrderedSchedule::walk_bound(int n_hot) const {
+#ifdef CU2REC_TEST_HOOKS  // (fault-path tests: a bound far too small, so that the sweeper does nearly all of the walk)
+    if (const char *env = std::getenv("CU2REC_BS_DBG"))
+        if (std::atoi(env) & 256) return 16;
+#endif
+    const int r = std::min(std::max(n_hot, 0), n_cols);
+    const double mean = std::max(0.0, static_cast<double>(n_active) - rank_rate_prefix[static_cast<size_t>(r)]);
+    const double bound = mean + 8.0 * std::sqrt(mean) + 64.0;
+    return bound >= static_cast<double>(n_active) ? n_active : static_cast<int>(bound);
+}
+
+// Blocks of 64 links an iteration's hot chains are expected to fill, as a bound that holds in all but astronomically rare iterations
+// (the hot links' count: mean rank_rate_prefix[n_hot_bs], variance at most the mean; one partial block per chain): what phase 3 is
+// launched with.  Its workgroups stride through the dense block table, so an iteration beyond the bound is still done completely.
+int OrderedSchedule::blocks_bound() const {
+#ifdef CU2REC_TEST_HOOKS  // (fault-path tests: a launch far too small, so that every workgroup strides over many blocks)
+    if (const char *env = std::getenv("CU2REC_BS_DBG"))
+        if (std::atoi(env) & 512) return std::min(3, max_blocks);
+#endif
+    const double mean = rank_rate_prefix[static_cast<size_t>(std::min(std::max(n_hot_bs, 0), n_cols))];
+    const double bound = (mean + 8.0 * std::sqrt(mean) + 64.0) / kBsLinks + n_hot_bs + 1;
+    return std::max(1, bound >= static_cast<double>(max_blocks) ? max_blocks : static_cast<int>(bound));
+}
+
 void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t stream, bool blocksolve) {
     if (n_active == 0) return;
     if (blocksolve && n_hot_bs == 0) blocksolve = false;  // nothing to solve block-wise: the ordered walk, bit for bit
@@ -922,6 +968,9 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
     const uint32_t item_mask = (1u << item_bits) - 1u;
     // ranks [0, n_hot) get a dedicated group each with deep prefetch; keep r + 1 representable in item_bits
     const int n_hot = std::min(std::min(n_cols, kHotChains), static_cast<int>(item_mask));
+    // positions the walk covers per iteration (its tail of the sorted order): behind the two-wave chains of either mode
+    const int walk_bound_plain = walk_bound(n_hot), walk_bound_bs = walk_bound(std::max(n_duo_bs, n_hot_bs));
+    const int launch_blocks = blocksolve ? blocks_bound() : 0;
     // Sample + sort (+ plan) of one window into a slot, on the schedule stream: nothing in it depends on the model.  The keys carry
     // the item's popularity rank only, and every iteration of the window is sorted as a segment of its own (stable, so users stay
     // ascending inside a chain); iteration b of the window occupies [b * n_rows, b * n_rows + n_active) of the sorted arrays.
@@ -1046,6 +1095,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                 it.ebuf = ebuf.ptr;
                 it.qstart = qstart.ptr;
                 it.max_blocks = max_blocks;
+                it.launch_blocks = launch_blocks;
                 const bool la_on = la_ranks > 0 && bs_lookahead_supported(a.nslots);  // (rows the rings have LDS for)
                 it.la_ranks = la_on ? la_ranks : 0;
                 it.la_cap = la_cap;
@@ -1070,7 +1120,7 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                     // (only the batch's last side kernel carries the event the main stream waits for at the END of the batch: an event
                     // on a kernel's completion signal holds the next packet of its queue back, here the signal kernel: 5.4 us)
                     launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, ranges,
-                                  b == nb - 1 ? ev_upd : nullptr);
+                                  b == nb - 1 ? ev_upd : nullptr, walk_bound_bs);
                     ++side_seq_host;
                     if (!(dbg & 16)) bs_launch_signal(side_seq.ptr, side_seq_host, upd);
                     bs_launch_update(a, it, stream);
@@ -1087,7 +1137,8 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
                         CU2REC_HIP(hipStreamWaitEvent(upd, ev_gram, 0));
                     }
                     if (!(dbg & 128))
-                        launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, ranges, ev_upd);
+                        launch_chains(a, it.keys, it.vals, n_active, item_of_rank.ptr, item_mask, std::max(n_duo_bs, n_hot_bs), upd, n_hot_bs, ranges, ev_upd,
+                                      walk_bound_bs);
                     else
                         CU2REC_HIP(hipEventRecord(ev_upd, upd));
                     if (!(dbg & 64)) bs_launch_update(a, it, stream);
@@ -1106,7 +1157,8 @@ void OrderedSchedule::run(SgdArgs a, uint64_t iter0, int n_iters, hipStream_t st
             if (b == std::min(2, nb - 1) && b > 0) schedule_next();
             a.iter0 = iter0 + done + b;
             launch_chains(a, sk + static_cast<size_t>(b) * seg, sv + static_cast<size_t>(b) * seg, n_active, item_of_rank.ptr, item_mask, n_hot, stream, 0,
-                          n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(off + b) * (n_range_ranks + 1) : nullptr);
+                          n_hot <= n_range_ranks ? chain_ranges[slot].ptr + static_cast<size_t>(off + b) * (n_range_ranks + 1) : nullptr, nullptr,
+                          walk_bound_plain);
         }
         schedule_next();
         CU2REC_HIP(hipGetLastError());

@@ -1,6 +1,8 @@
 // Workspace + driver of the ordered (sequential-semantics, deterministic) SGD mode; see ordered.hip.
 #pragma once
 
+#include <vector>
+
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
@@ -69,6 +71,11 @@ struct OrderedSchedule {
     // popular items (chain_ranges_kernel, behind the sort): the two-wave blocks read their chain's range instead of searching
     DeviceBuffer<int> chain_ranges[2];
     int n_range_ranks = 0;
+    // rank_rate_prefix[r] = expected updates per iteration of the r most popular items together (host; [n_cols + 1]): what the walk
+    // behind rank r has to cover is n_active minus that, give or take its square root (walk_bound)
+    std::vector<double> rank_rate_prefix;
+    int walk_bound(int n_hot) const;
+    int blocks_bound() const;  // workgroups phase 3 of a block-solve iteration is launched with (BsIteration::launch_blocks)
     DeviceBuffer<BsChainDesc> bs_chains[2];
     DeviceBuffer<BsBlockDesc> bs_blocks[2];
     DeviceBuffer<float> tables, Mbuf, ebuf, qstart;

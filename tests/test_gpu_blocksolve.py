@@ -511,6 +511,57 @@ def test_blocksolve_join_wait_that_is_never_satisfied_ends_in_ehip_and_the_proce
     assert lines[-1].startswith("HEALED ") and float(lines[-1].split()[1]) <= 2e-6, lines[-1]
 
 
+_SWEEP_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import cu2rec_amd as cu
+from cu2rec_amd import api, synth
+from cu2rec_amd._lib import check, lib
+from oracle import oracle as orc
+hyper = (0.01, 0.02, 0.02, 0.02, 0.02)
+worst = 0.0
+for users, items, nnz, f, iters, rate in ((3000, 400, 30000, 100, 5, 4.0), (20000, 3000, 90000, 16, 4, 8.0), (6000, 5000, 40000, 50, 70, 1e9),
+                                          (9000, 6, 40000, 100, 3, 1.0), (9000, 6, 40000, 128, 3, 1.0), (2000, 300, 40000, 200, 5, 0.5)):
+    api.blocksolve_min_rate(rate)
+    api.blocksolve_lookahead_blocks(2 if f == 100 else 0)
+    tr, _ = synth.make_ratings(users, items, nnz, min_degree=3, seed=users + f)
+    d_tr = cu.DeviceCSR(tr)
+    state = orc.init_model(tr.rows, tr.cols, f)
+    orc.sgd_iterations(orc.CSR(tr.indptr, tr.indices, tr.data, tr.rows, tr.cols, tr.global_bias), *state, tr.global_bias, hyper, 42, 0,
+                       iters, dot_order=orc.DOT_TREE16)
+    exact = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    exact.sgd(d_tr, hyper, 42, 0, iters, mode="ordered")
+    for g, w in zip(exact.download(), state):
+        assert np.array_equal(g, w), "ordered mode with the walk swept by one workgroup differs from the oracle"
+    model = cu.Model(tr.rows, tr.cols, f, tr.global_bias)
+    model.sgd(d_tr, hyper, 42, 0, iters, mode="blocksolve")
+    check(lib().cu2rec_check_faults())
+    worst = max(worst, max(float(np.abs(g.astype(np.float64) - w).max()) for g, w in zip(model.download(), state)))
+print("OK %%.3e" %% worst)
+"""
+
+
+def test_launch_bounds_too_small_are_swept_and_change_nothing():
+    """The walk of an iteration covers only the TAIL of the sorted order, as long as the host expects it to be (OrderedSchedule::walk_bound:
+    mean + 8 sigma of the positions behind the two-wave chains); what an iteration has in front of that is swept by one extra workgroup.
+    The bound is about speed, never about results: in the test build CU2REC_BS_DBG=256 cuts it to 16 positions, so the sweeper does
+    nearly the whole walk -- thousands of short chains -- and the ordered mode still equals the oracle bit for bit, the block-solve mode
+    within its rounding, on sets with hundreds to thousands of walked items.  Likewise phases 1 and 3 of a block-solve iteration are
+    launched with the EXPECTED number of blocks (OrderedSchedule::blocks_bound) and stride through the dense block table: with the
+    launch cut to 3 workgroups (bit 512) every one of them does many blocks in turn, LDS tiles reused -- same results."""
+    import subprocess
+    import sys
+    hooks = os.path.join(ROOT, "build", "test", "libcu2rec_amd_hooks.so")
+    assert os.path.exists(hooks), "build/test/libcu2rec_amd_hooks.so is missing: run __graft_entry__.build()"
+    env = dict(os.environ, CU2REC_BS_DBG="768", CU2REC_AMD_LIB=hooks)
+    res = subprocess.run([sys.executable, "-c", _SWEEP_SCRIPT % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    last = res.stdout.strip().splitlines()[-1]
+    assert last.startswith("OK ") and float(last.split()[1]) <= 2e-6, last
+
+
 def test_blocksolve_gate_that_never_opens_only_costs_time():
     """The side stream's gate kernel guards timing, not data: one that can never be satisfied (CU2REC_BS_DBG=32) gives up after the
     bound and the run goes on -- no error, and the result is the oracle's within the mode's usual rounding (a gate
