@@ -223,7 +223,9 @@ def profile_traffic(workload, factors, mode):
                     parts.append("%s %.1f MB" % (name, b / 1e6))
     if not parts:
         return None, "%s lists none of the iteration's kernels" % rel
-    return total, "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units, FETCH doubled; per launch: %s)" % (rel, ", ".join(parts))
+    return total, ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, KiB units, FETCH doubled; EVENT TOPOLOGY: under a counter pass the "
+                   "library forks / joins the side stream with events, the timed region uses the device-side gate and join -- same kernels, same bytes; "
+                   "per launch: %s)" % (rel, ", ".join(parts)))
 
 
 def profile_kernels(workload, factors, mode):
