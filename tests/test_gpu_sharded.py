@@ -59,6 +59,15 @@ def test_rccl_world1_allreduce_in_the_loop(monkeypatch):
     job.run(HYPER, 42, 0, 23, mode="ordered")
     info = job.info()
     assert info["exchanges"] == 4 and info["wire_bytes"] == tr.cols * (f + 1) * 4
+    # what RCCL itself says about the communicator (cu2rec_comm_info: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion)
+    ci = comm.info()
+    assert (ci["rank"], ci["nranks"], ci["rccl_nranks"], ci["rccl_rank"], ci["is_callback"]) == (0, 1, 1, 0, 0), ci
+    assert ci["rccl_version"] >= 20000 and ci["rccl_device"] >= 0, ci
+    # ... and every exchange was timed by its event pair (cu2rec_shard_job_exchange_stats)
+    import torch
+    torch.cuda.synchronize()
+    xs = job.exchange_stats()
+    assert xs["timed"] == 4 and 0 < xs["max_seconds"] <= xs["seconds"] < 1.0, xs
     assert info["users_total"] == np.count_nonzero(np.diff(tr.indptr)) and info["nnz_total"] == tr.nnz
     P, Q, ub, ib = orc.init_model(tr.rows, tr.cols, f)
     orc.sgd_iterations(_as_orc(tr), P, Q, ub, ib, tr.global_bias, HYPER, 42, 0, 23, dot_order=orc.DOT_TREE16)
